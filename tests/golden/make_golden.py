@@ -1,0 +1,162 @@
+"""Generate golden vectors for the hot path from the REAL reference (build container only).
+
+Run:  python tests/golden/make_golden.py          (needs /root/reference; writes tests/golden/*.json)
+
+The reference's trainer module imports packages that are absent here and irrelevant to the
+hot path (mlflow, xarray, pytorch_msssim, torchvision) and a staging module whose import
+asserts CUDA and loads NetCDF files.  They are satisfied with inert
+placeholder modules *before* import; none of them is on the path being recorded.  What is
+recorded is computed exclusively by the reference's own ``Generator``, ``Critic`` and
+``WassersteinGAN`` code with this repo's deterministic synthetic weights/tiles/alphas.
+The fixtures are data only (scalars, norms, sampled entries, checksums).
+"""
+from __future__ import annotations
+
+import importlib.machinery
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("DOWNGAN_REFERENCE", "/root/reference")
+
+from downgan_amd import synthetic  # noqa: E402
+
+
+class _Any:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Any()
+
+    def __getattr__(self, n):
+        return _Any()
+
+
+class _Inert(types.ModuleType):
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Any
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    for name in ["mlflow", "mlflow.tracking", "mlflow.pytorch", "pytorch_msssim", "xarray",
+                 "torchvision", "torchvision.utils", "DoWnGAN.GAN.stage"]:
+        m = _Inert(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        m.__path__ = []
+        sys.modules[name] = m
+    import DoWnGAN.config.config as config
+    import DoWnGAN.config.hyperparams as hp
+    import DoWnGAN.GAN.wasserstein as W
+    from DoWnGAN.networks.critic import Critic
+    from DoWnGAN.networks.generator import Generator
+    torch.autograd.set_detect_anomaly(False)  # numerically inert
+    config.device = torch.device("cpu")
+    return config, hp, W, Generator, Critic
+
+
+def _sample_idx(n):
+    return sorted({0, n // 3, (2 * n) // 3, n - 1})
+
+
+def _tensor_summary(t):
+    f = t.detach().double().flatten()
+    idx = _sample_idx(f.numel())
+    return {"l2": float(f.norm()), "sum": float(f.sum()), "abs_sum": float(f.abs().sum()),
+            "idx": idx, "val": [float(f[i]) for i in idx]}
+
+
+def run_config(name, B, S, F_, cin, nrb, steps, config, hp, W, Generator, Critic):
+    hp.batch_size = B
+    G = Generator(F_, 8 * S, cin, 2, num_res_blocks=nrb)
+    C = Critic(F_, 8 * S, 2)
+    pg = synthetic.generator_params(F_, cin, 2, nrb)
+    pc = synthetic.critic_params(F_, 8 * S, 2)
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in pg.items()})
+    C.load_state_dict({k: torch.from_numpy(v) for k, v in pc.items()})
+    Gopt = torch.optim.Adam(G.parameters(), hp.lr, betas=(0.9, 0.99))   # stage.py:63
+    Copt = torch.optim.Adam(C.parameters(), hp.lr, betas=(0.9, 0.99))   # stage.py:64
+    tr = W.WassersteinGAN(G, C, Gopt, Copt)
+    coarse_np, fine_np = synthetic.tiles(B, cin, S, mask_channel=(2 if cin > 2 else None))
+    coarse, fine = torch.from_numpy(coarse_np), torch.from_numpy(fine_np)
+
+    out = {"config": {"B": B, "S": S, "F": F_, "cin": cin, "num_res_blocks": nrb, "steps": steps},
+           "forward": {}, "steps": []}
+    with torch.no_grad():
+        out["forward"]["G_coarse"] = _tensor_summary(G(coarse))
+        out["forward"]["C_fine"] = {"values": [float(v) for v in C(fine).flatten()]}
+
+    c_outs = []
+    C.register_forward_hook(lambda m, i, o: c_outs.append(o.detach().clone()))
+    gp_rets = []
+    orig_gp = tr._gp
+
+    def gp_wrap(real, fake, critic):
+        r = orig_gp(real, fake, critic)
+        gp_rets.append(float(r))
+        return r
+    tr._gp = gp_wrap
+    orig_rand = torch.rand
+
+    for step in range(steps):
+        a = torch.from_numpy(synthetic.alpha(B, step))
+        torch.rand = lambda *args, **kw: a.view(B, 1, 1, 1).clone().requires_grad_(True)  # wasserstein.py:91
+        try:
+            c_outs.clear(); gp_rets.clear()
+            tr._critic_train_iteration(coarse, fine)
+        finally:
+            torch.rand = orig_rand
+        c_real, c_fake, _c_int = c_outs
+        rec = {"step": step,
+               "c_real_mean": float(c_real.mean()), "c_fake_mean": float(c_fake.mean()),
+               "gp_ret": gp_rets[0]}
+        rec["gradient_penalty"] = hp.gp_lambda * rec["gp_ret"]
+        rec["critic_loss"] = float(c_fake.mean() - c_real.mean() + hp.gp_lambda * gp_rets[0])
+        rec["w_estimate"] = float(c_real.mean() - c_fake.mean())
+        rec["C_grads"] = {k: _tensor_summary(p.grad) for k, p in C.named_parameters()}
+        rec["C_params_after"] = {k: _tensor_summary(p) for k, p in C.named_parameters()}
+        if tr.num_steps % hp.critic_iterations == 0:          # wasserstein.py:136
+            c_outs.clear()
+            with torch.no_grad():
+                fake_pre = G(coarse)
+                cl = float(torch.nn.functional.l1_loss(fake_pre, fine))
+            c_outs.clear()
+            tr._generator_train_iteration(coarse, fine)
+            c_fake_g = c_outs[0]
+            rec["g_c_fake_mean"] = float(c_fake_g.mean())
+            rec["content_loss"] = cl
+            rec["g_loss"] = float(-c_fake_g.mean() * hp.gamma + hp.content_lambda * cl)
+            gsum = {k: _tensor_summary(p.grad) for k, p in G.named_parameters()}
+            rec["G_grads"] = {k: {"l2": v["l2"], "idx": v["idx"], "val": v["val"]} for k, v in gsum.items()}
+            rec["G_params_after"] = {k: {"l2": s["l2"], "sum": s["sum"]} for k, s in
+                                     ((k, _tensor_summary(p)) for k, p in G.named_parameters())}
+        tr.num_steps += 1
+        out["steps"].append(rec)
+        print(name, {k: v for k, v in rec.items() if not isinstance(v, dict)}, flush=True)
+    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
+        json.dump(out, f)
+
+
+def main():
+    config, hp, W, Generator, Critic = _import_reference()
+    torch.set_num_threads(os.cpu_count())
+    # cfg1 of BASELINE.json: batch 4, 2ch 16x16 -> 128x128, filters 16 (stage.py:59-60), steps 0..5
+    run_config("cfg1", 4, 16, 16, 2, 16, 6, config, hp, W, Generator, Critic)
+    # 6-covariate input (cfg4's channel count), 2 RRDBs, 1 step: exercises Cin=6 and ragged channel padding
+    run_config("cin6_small", 2, 16, 16, 6, 2, 1, config, hp, W, Generator, Critic)
+    # a wider/shallower net at a different tile size: filters 32, 32x32 -> 256x256, 1 RRDB, 2 steps
+    run_config("f32_s32", 2, 32, 32, 2, 1, 2, config, hp, W, Generator, Critic)
+
+
+if __name__ == "__main__":
+    main()
