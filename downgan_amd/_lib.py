@@ -1,0 +1,96 @@
+"""ctypes binding of libdowngan_hip.so (the C ABI declared in include/downgan_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C downgan_amd/csrc``.
+There is no fallback: if the shared object is missing, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdowngan_hip.so")
+
+DG_F32, DG_BF16 = 0, 1
+STATUS = {0: "DG_OK", -1: "DG_ERR_BAD_SHAPE", -2: "DG_ERR_BAD_DTYPE", -3: "DG_ERR_BAD_ARG", -4: "DG_ERR_LAUNCH"}
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("has_act", C.c_int), ("act_slope", C.c_float),
+                ("r1", C.c_void_p), ("ldr1", C.c_int64), ("s1", C.c_float),
+                ("r2", C.c_void_p), ("ldr2", C.c_int64), ("s2", C.c_float),
+                ("mask", C.c_void_p), ("ldmask", C.c_int64), ("mask_slope", C.c_float),
+                ("accumulate", C.c_int)]
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("Cin", C.c_int), ("Cout", C.c_int), ("stride", C.c_int), ("pixel_shuffle", C.c_int),
+                ("ldx", C.c_int64), ("ldy", C.c_int64)]
+
+
+class GGDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("Hs", C.c_int), ("Ws", C.c_int), ("Cred", C.c_int),
+                ("lds", C.c_int64), ("src_ps", C.c_int),
+                ("Hg", C.c_int), ("Wg", C.c_int), ("sy_mul", C.c_int), ("sx_mul", C.c_int),
+                ("ntaps", C.c_int), ("tap_dy", C.c_int * 9), ("tap_dx", C.c_int * 9), ("tap_w", C.c_int * 9),
+                ("Nout", C.c_int), ("ldw", C.c_int64),
+                ("Hd", C.c_int), ("Wd", C.c_int), ("ldd", C.c_int64),
+                ("dy_mul", C.c_int), ("dx_mul", C.c_int), ("dy_off", C.c_int), ("dx_off", C.c_int),
+                ("dst_ps", C.c_int)]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_PROTOS = {
+    "dg_conv3x3_fwd": [C.POINTER(ConvGeom), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
+    "dg_conv3x3_dgrad": [C.POINTER(ConvGeom), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
+    "dg_conv3x3_wgrad": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp],
+    "dg_gather_gemm": [C.POINTER(GGDesc), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
+    "dg_conv3x3_plan": [C.POINTER(ConvGeom), _i, C.POINTER(GGDesc)],
+    "dg_colsum": [_i, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp],
+    "dg_repack_conv_weights": [_i, _i, _vp, _vp, _i, _i, _vp],
+    "dg_linear_fwd": [_i, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i64, _vp],
+    "dg_linear_dx": [_i, _i, _vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _f, _i, _i, _i64, _vp],
+    "dg_linear_dw": [_i, _vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i64, _vp],
+    "dg_bias_act": [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _f, _vp],
+    "dg_mask_mul": [_i, _vp, _i64, _vp, _i64, _i64, _i, _f, _vp],
+    "dg_axpby": [_i, _vp, _i64, _vp, _i64, _f, _vp, _i64, _f, _i64, _i, _vp],
+    "dg_gp_interp": [_i, _vp, _vp, _vp, _vp, _i, _i64, _vp],
+    "dg_sumsq_rows": [_i, _vp, _i, _i64, _vp, _vp],
+    "dg_gp_finish": [_vp, _i, _i, _f, _f, _vp, _vp, _vp],
+    "dg_scale_rows": [_i, _vp, _vp, _vp, _i, _i64, _vp],
+    "dg_l1": [_i, _vp, _i64, _vp, _i64, _i64, _i, _vp, _vp, _i64, _f, _vp, _i64, _vp],
+    "dg_sum_strided": [_vp, _i, _i, _f, _vp, _vp],
+    "dg_fill_col": [_vp, _i, _i, _i, _f, _vp],
+    "dg_adam": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp],
+    "dg_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "dg_nhwc_to_nchw": [_i, _vp, _i64, _vp, _i, _i, _i, _i, _vp],
+    "dg_cast": [_i, _vp, _vp, _i64, _vp],
+}
+EXPORTS = ["dg_version"] + list(_PROTOS)
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C downgan_amd/csrc`. downgan_amd has no CPU or eager fallback.")
+        l = C.CDLL(LIB_PATH)
+        l.dg_version.restype = C.c_char_p
+        l.dg_version.argtypes = []
+        for name, args in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype = C.c_int
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {STATUS.get(rc, rc)}")

@@ -1,0 +1,69 @@
+// Internal helpers shared by the HIP translation units of libdowngan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/downgan_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int EPC = 4; static constexpr int id = DG_F32; };
+template <> struct DT<bf16_t> { static constexpr int EPC = 8; static constexpr int id = DG_BF16; };
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+// round-to-nearest-even; NaN stays NaN (the plain integer trick maps some NaNs to inf/0)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float ld_elem(const float* p) { return *p; }
+__device__ __forceinline__ float ld_elem(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ void st_elem(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_elem(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// 4 consecutive elements <-> float[4]
+__device__ __forceinline__ void ld4(const float* p, float* v) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, float* v) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4(bf16_t* p, const float* v) {
+  uint2 t;
+  t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+  t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = t;
+}
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float leaky_grad(float y, float slope) { return y > 0.f ? 1.f : slope; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int dg_check_launch() { return hipGetLastError() == hipSuccess ? DG_OK : DG_ERR_LAUNCH; }
+
+// bijective XCD-aware remap of a linear block id: blocks that share an XCD (id % 8 equal) get a
+// contiguous range of logical tiles, so neighbouring tiles share that XCD's L2 (speed only).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}

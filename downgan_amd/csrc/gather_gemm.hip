@@ -1,0 +1,386 @@
+// Gather-GEMM: the one MFMA kernel every 3x3 conv forward and data-gradient is lowered to.
+//
+//   Y[dst(m), n] = epilogue( sum_{t<ntaps} sum_{c<Cred} X[src(m,t), c] * Wp[n][tap_w[t]][c] )
+//
+// GEMM view: rows m = output pixels (img,gy,gx), columns n = output channels,
+// reduction K = taps x channels, walked in 16-byte "chunks" (8 bf16 / 4 fp32 channels) so that the
+// same staging code serves both precisions:
+//   bf16 : v_mfma_f32_16x16x32_bf16  (one MFMA per 16-B fragment pair)
+//   fp32 : v_mfma_f32_16x16x4_f32    (four MFMAs per 16-B fragment pair; exact fp32, parity mode)
+// The K order inside a fragment is a permutation of the natural one; both operands use the same
+// permutation, so the sum is unchanged up to fp32 re-association.
+//
+// Tile: BP pixels x BC channels per 256-thread workgroup (4 waves), K-step = 8 chunks (128 B per
+// row).  NHWC makes every 128-B row piece a full contiguous line of one source pixel.  Operands are
+// staged global -> registers -> LDS (double buffered, one barrier per K-step; the global loads of
+// step k+1 are in flight while step k computes).  LDS rows are 128 B, XOR-swizzled by
+// chunk ^= (row>>1)&7 so that the 16 lanes of a ds_read_b128 group hit 16 different 16-B slots.
+// MFMA orientation: A = weights (rows = channels), B = pixels: each lane then owns 4 CONSECUTIVE
+// channels of one pixel in the accumulator, so the epilogue loads/stores 8-16 B vectors.
+#include "dg_internal.h"
+
+struct GGArgs {
+  const void* x; const void* w; void* y;
+  const float* bias; const void* r1; const void* r2; const void* mask;
+  long long ldx, ldw, ldy, ldr1, ldr2, ldmask;
+  int M, Hg, Wg, Hs, Ws;
+  int cch, kchunks, Cred, ntaps;
+  int sy_mul, sx_mul;
+  unsigned long long tap_lo; unsigned tap_hi;
+  int Nout, Hd, Wd, dy_mul, dx_mul, dy_off, dx_off;
+  int src_ps, dst_ps, cps_src_chunks, cps_dst;
+  int has_act, accumulate;
+  float act_slope, s1, s2, mask_slope;
+  unsigned nwg, nct;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BP, int BC, int WP, int WC>
+__global__ __launch_bounds__(256) void gg_kernel(const GGArgs a) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int NPW = BP / WP;
+  constexpr int FP = WP / 16, FC = WC / 16;
+  constexpr int PR = BP / 32;
+  constexpr int CR = (BC + 31) / 32;
+  constexpr int ROWS = BP + BC;
+  static_assert((BP / WP) * (BC / WC) == 4, "4 waves per workgroup");
+  __shared__ uint4 smem[2 * ROWS * 8];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tile_c = tile % a.nct, tile_p = tile / a.nct;
+  const int p0 = tile_p * BP, c0 = tile_c * BC;
+  const int cc = tid & 7, r0 = tid >> 3;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ Wt = reinterpret_cast<const T*>(a.w);
+
+  int sy0[PR], sx0[PR], img[PR];
+#pragma unroll
+  for (int i = 0; i < PR; ++i) {
+    int m = p0 + r0 + 32 * i;
+    if (m < a.M) {
+      int gx = m % a.Wg, t = m / a.Wg;
+      int gy = t % a.Hg;
+      img[i] = t / a.Hg;
+      sy0[i] = gy * a.sy_mul;
+      sx0[i] = gx * a.sx_mul;
+    } else {
+      img[i] = -1; sy0[i] = 0; sx0[i] = 0;
+    }
+  }
+  int tap = cc / a.cch, c8 = cc % a.cch;
+
+  uint4 ra[PR], rb[CR];
+
+  auto gload = [&]() {
+    const bool kok = tap < a.ntaps;
+    unsigned code = 0;
+    if (kok) code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
+    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1, ws = (int)(code >> 4);
+    int q = 0, cq = c8;
+    if (a.src_ps) { q = c8 / a.cps_src_chunks; cq = c8 - q * a.cps_src_chunks; }
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      const int sy = sy0[i] + dy, sx = sx0[i] + dx;
+      const bool ok = kok && img[i] >= 0 && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+      long long off;
+      if (!a.src_ps) off = ((long long)(img[i] * a.Hs + sy) * a.Ws + sx) * a.ldx + c8 * EPC;
+      else off = (((long long)(img[i] * 2 * a.Hs + 2 * sy + (q >> 1))) * (2 * a.Ws) + 2 * sx + (q & 1)) * a.ldx + cq * EPC;
+      // always-valid address + value select: keeps the staging registers out of scratch
+      uint4 v = *reinterpret_cast<const uint4*>(X + (ok ? off : 0ll));
+      ra[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < CR; ++i) {
+      const int row = r0 + 32 * i, n = c0 + row;
+      const bool ok = kok && row < BC && n < a.Nout;
+      const long long woff = (long long)n * a.ldw + (long long)ws * a.Cred + c8 * EPC;
+      uint4 v = *reinterpret_cast<const uint4*>(Wt + (ok ? woff : 0ll));
+      rb[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+    c8 += 8;
+    while (c8 >= a.cch) { c8 -= a.cch; ++tap; }
+  };
+  auto lstore = [&](int buf) {
+    uint4* s = smem + buf * ROWS * 8;
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      const int row = r0 + 32 * i;
+      s[row * 8 + (cc ^ ((row >> 1) & 7))] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CR; ++i) {
+      const int row = r0 + 32 * i;
+      if (row < BC) s[(BP + row) * 8 + (cc ^ ((row >> 1) & 7))] = rb[i];
+    }
+  };
+
+  f32x4_t acc[FC][FP];
+#pragma unroll
+  for (int j = 0; j < FC; ++j)
+#pragma unroll
+    for (int i = 0; i < FP; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int wp = wave % NPW, wc = wave / NPW;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nk = (a.kchunks + 7) >> 3;
+
+  gload();
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int ks = 0; ks < nk; ++ks) {
+    const bool more = ks + 1 < nk;
+    if (more) gload();
+    const uint4* s = smem + cur * ROWS * 8;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = kk * 4 + g;
+      uint4 fa[FC], fb[FP];
+#pragma unroll
+      for (int j = 0; j < FC; ++j) {
+        const int row = wc * WC + 16 * j + l15;
+        fa[j] = s[(BP + row) * 8 + (ch ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < FP; ++i) {
+        const int row = wp * WP + 16 * i + l15;
+        fb[i] = s[row * 8 + (ch ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < FC; ++j)
+#pragma unroll
+        for (int i = 0; i < FP; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane owns channels co0..co0+3 of pixel m for each (j,i) fragment
+  T* Y = reinterpret_cast<T*>(a.y);
+  const T* R1 = reinterpret_cast<const T*>(a.r1);
+  const T* R2 = reinterpret_cast<const T*>(a.r2);
+  const T* MK = reinterpret_cast<const T*>(a.mask);
+#pragma unroll
+  for (int i = 0; i < FP; ++i) {
+    const int m = p0 + wp * WP + 16 * i + l15;
+    if (m >= a.M) continue;
+    const int gx = m % a.Wg, t = m / a.Wg;
+    const int gy = t % a.Hg, n = t / a.Hg;
+#pragma unroll
+    for (int j = 0; j < FC; ++j) {
+      const int co0 = c0 + wc * WC + 16 * j + 4 * g;
+      if (co0 >= a.Nout) continue;
+      int py, px, c;
+      if (a.dst_ps) {
+        const int q = co0 / a.cps_dst;
+        c = co0 - q * a.cps_dst;
+        py = gy * 2 + (q >> 1); px = gx * 2 + (q & 1);
+      } else {
+        c = co0; py = gy * a.dy_mul + a.dy_off; px = gx * a.dx_mul + a.dx_off;
+      }
+      const long long pix = ((long long)n * a.Hd + py) * a.Wd + px;
+      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+      if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + co0);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (a.has_act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], a.act_slope);
+      }
+      if (R1) {
+        float r[4]; ld4(R1 + pix * a.ldr1 + c, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s1 + r[e];
+      }
+      if (R2) {
+        float r[4]; ld4(R2 + pix * a.ldr2 + c, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
+      }
+      if (MK) {
+        float r[4]; ld4(MK + pix * a.ldmask + c, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
+      }
+      if (a.accumulate) {
+        float r[4]; ld4(Y + pix * a.ldy + c, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      st4(Y + pix * a.ldy + c, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ host side
+static int gg_validate(const dg_gg_desc* d) {
+  if (d->dtype != DG_F32 && d->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  const int epc = d->dtype == DG_F32 ? 4 : 8;
+  if (d->N <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Hd <= 0 || d->Wd <= 0) return DG_ERR_BAD_SHAPE;
+  if (d->Cred <= 0 || d->Cred % 8 || d->Nout <= 0 || d->Nout % 16) return DG_ERR_BAD_SHAPE;
+  if (d->ntaps < 1 || d->ntaps > 9) return DG_ERR_BAD_SHAPE;
+  if (d->lds % epc || d->ldd % 4 || d->ldw % epc) return DG_ERR_BAD_SHAPE;
+  for (int t = 0; t < d->ntaps; ++t) {
+    if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1) return DG_ERR_BAD_ARG;
+    if (d->tap_w[t] < 0 || d->tap_w[t] > 8) return DG_ERR_BAD_ARG;
+  }
+  if (d->src_ps && ((d->Cred / 4) % 8)) return DG_ERR_BAD_SHAPE;
+  if (d->dst_ps && ((d->Nout / 4) % 16)) return DG_ERR_BAD_SHAPE;
+  if ((long long)d->N * d->Hg * d->Wg >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
+  // every destination pixel must be inside the destination tensor
+  if (d->dst_ps) {
+    if (2 * d->Hg > d->Hd || 2 * d->Wg > d->Wd) return DG_ERR_BAD_SHAPE;
+  } else {
+    if ((d->Hg - 1) * d->dy_mul + d->dy_off >= d->Hd || (d->Wg - 1) * d->dx_mul + d->dx_off >= d->Wd) return DG_ERR_BAD_SHAPE;
+    if (d->dy_off < 0 || d->dx_off < 0 || d->dy_mul < 1 || d->dx_mul < 1) return DG_ERR_BAD_SHAPE;
+  }
+  return DG_OK;
+}
+
+template <typename T, int BP, int BC, int WP, int WC>
+static int gg_launch_t(GGArgs& a, hipStream_t st) {
+  a.nct = (unsigned)((a.Nout + BC - 1) / BC);
+  const unsigned npt = (unsigned)((a.M + BP - 1) / BP);
+  a.nwg = a.nct * npt;
+  hipLaunchKernelGGL((gg_kernel<T, BP, BC, WP, WC>), dim3(a.nwg), dim3(256), 0, st, a);
+  return dg_check_launch();
+}
+
+template <typename T>
+static int gg_launch(GGArgs& a, hipStream_t st) {
+  if (a.Nout > 64) return gg_launch_t<T, 128, 128, 64, 64>(a, st);
+  if (a.Nout > 32) return gg_launch_t<T, 128, 64, 64, 32>(a, st);
+  if (a.Nout > 16) return gg_launch_t<T, 128, 32, 32, 32>(a, st);
+  return gg_launch_t<T, 128, 16, 32, 16>(a, st);
+}
+
+extern "C" int dg_gather_gemm(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w,
+                              void* y, void* stream) {
+  if (!d || !x || !w || !y) return DG_ERR_BAD_ARG;
+  int rc = gg_validate(d);
+  if (rc) return rc;
+  const int epc = d->dtype == DG_F32 ? 4 : 8;
+  GGArgs a{};
+  a.x = x; a.w = w; a.y = y;
+  a.ldx = d->lds; a.ldw = d->ldw; a.ldy = d->ldd;
+  a.M = d->N * d->Hg * d->Wg; a.Hg = d->Hg; a.Wg = d->Wg; a.Hs = d->Hs; a.Ws = d->Ws;
+  a.Cred = d->Cred; a.cch = d->Cred / epc; a.ntaps = d->ntaps; a.kchunks = d->ntaps * a.cch;
+  a.sy_mul = d->sy_mul; a.sx_mul = d->sx_mul;
+  a.tap_lo = 0; a.tap_hi = 0;
+  for (int t = 0; t < d->ntaps; ++t) {
+    unsigned long long code = (unsigned)(d->tap_dy[t] + 1) | ((unsigned)(d->tap_dx[t] + 1) << 2) | ((unsigned)d->tap_w[t] << 4);
+    if (t < 8) a.tap_lo |= code << (8 * t); else a.tap_hi = (unsigned)code;
+  }
+  a.Nout = d->Nout; a.Hd = d->Hd; a.Wd = d->Wd;
+  a.dy_mul = d->dy_mul; a.dx_mul = d->dx_mul; a.dy_off = d->dy_off; a.dx_off = d->dx_off;
+  a.src_ps = d->src_ps; a.dst_ps = d->dst_ps;
+  a.cps_src_chunks = d->src_ps ? d->Cred / 4 / epc : 1;
+  a.cps_dst = d->dst_ps ? d->Nout / 4 : d->Nout;
+  a.s1 = a.s2 = 1.f; a.mask_slope = 1.f; a.act_slope = 1.f;
+  if (ep) {
+    a.bias = ep->bias; a.has_act = ep->has_act; a.act_slope = ep->act_slope;
+    a.r1 = ep->r1; a.ldr1 = ep->ldr1; a.s1 = ep->s1;
+    a.r2 = ep->r2; a.ldr2 = ep->ldr2; a.s2 = ep->s2;
+    a.mask = ep->mask; a.ldmask = ep->ldmask; a.mask_slope = ep->mask_slope;
+    a.accumulate = ep->accumulate;
+    if ((a.r1 && a.ldr1 % 4) || (a.r2 && a.ldr2 % 4) || (a.mask && a.ldmask % 4)) return DG_ERR_BAD_SHAPE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return d->dtype == DG_F32 ? gg_launch<float>(a, st) : gg_launch<bf16_t>(a, st);
+}
+
+static int geom_validate(const dg_conv_geom* g) {
+  if (!g) return DG_ERR_BAD_ARG;
+  if (g->dtype != DG_F32 && g->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  if (g->N <= 0 || g->H <= 0 || g->W <= 0) return DG_ERR_BAD_SHAPE;
+  if (g->stride != 1 && g->stride != 2) return DG_ERR_BAD_SHAPE;
+  if (g->stride == 2 && ((g->H | g->W) & 1)) return DG_ERR_BAD_SHAPE;
+  if (g->Cin <= 0 || g->Cin % 8 || g->Cout <= 0 || g->Cout % 16) return DG_ERR_BAD_SHAPE;
+  if (g->pixel_shuffle && (g->stride != 1 || (g->Cout / 4) % 16)) return DG_ERR_BAD_SHAPE;
+  return DG_OK;
+}
+
+extern "C" int dg_conv3x3_plan(const dg_conv_geom* g, int kind, dg_gg_desc* out) {
+  int rc = geom_validate(g);
+  if (rc) return rc;
+  if (!out || (kind != 0 && kind != 1)) return DG_ERR_BAD_ARG;
+  const int Ho = g->H / g->stride, Wo = g->W / g->stride;
+  if (kind == 0) {
+    dg_gg_desc d{};
+    d.dtype = g->dtype; d.N = g->N; d.Hs = g->H; d.Ws = g->W; d.Cred = g->Cin; d.lds = g->ldx; d.src_ps = 0;
+    d.Hg = Ho; d.Wg = Wo; d.sy_mul = g->stride; d.sx_mul = g->stride;
+    d.ntaps = 9;
+    for (int r = 0; r < 3; ++r)
+      for (int s = 0; s < 3; ++s) { d.tap_dy[r * 3 + s] = r - 1; d.tap_dx[r * 3 + s] = s - 1; d.tap_w[r * 3 + s] = r * 3 + s; }
+    d.Nout = g->Cout; d.ldw = 9ll * g->Cin;
+    d.ldd = g->ldy; d.dy_mul = d.dx_mul = 1; d.dy_off = d.dx_off = 0;
+    if (g->pixel_shuffle) { d.dst_ps = 1; d.Hd = 2 * Ho; d.Wd = 2 * Wo; }
+    else { d.dst_ps = 0; d.Hd = Ho; d.Wd = Wo; }
+    out[0] = d;
+    return 1;
+  }
+  // data gradient: source = dy over the Ho x Wo output grid, destination = dx over H x W
+  int nd = 0;
+  const int st = g->stride;
+  for (int ph = 0; ph < st; ++ph)
+    for (int pw = 0; pw < st; ++pw) {
+      dg_gg_desc d{};
+      d.dtype = g->dtype; d.N = g->N; d.Hs = Ho; d.Ws = Wo; d.Cred = g->Cout; d.lds = g->ldy;
+      d.src_ps = g->pixel_shuffle;
+      d.Hg = g->H / st; d.Wg = g->W / st; d.sy_mul = 1; d.sx_mul = 1;
+      d.ntaps = 0;
+      for (int r = 0; r < 3; ++r) {
+        if ((ph + 1 - r) % st) continue;
+        for (int s = 0; s < 3; ++s) {
+          if ((pw + 1 - s) % st) continue;
+          // ho = (hi + 1 - r)/st with hi = gy*st + ph
+          d.tap_dy[d.ntaps] = (ph + 1 - r) / st; d.tap_dx[d.ntaps] = (pw + 1 - s) / st;
+          d.tap_w[d.ntaps] = r * 3 + s;
+          ++d.ntaps;
+        }
+      }
+      d.Nout = g->Cin; d.ldw = 9ll * g->Cout;
+      d.Hd = g->H; d.Wd = g->W; d.ldd = g->ldx;
+      d.dy_mul = d.dx_mul = st; d.dy_off = ph; d.dx_off = pw; d.dst_ps = 0;
+      out[nd++] = d;
+    }
+  return nd;
+}
+
+extern "C" int dg_conv3x3_fwd(const dg_conv_geom* g, const dg_epilogue* ep, const void* x, const void* w_fwd,
+                              void* y, void* stream) {
+  dg_gg_desc d[4];
+  int n = dg_conv3x3_plan(g, 0, d);
+  if (n < 0) return n;
+  return dg_gather_gemm(&d[0], ep, x, w_fwd, y, stream);
+}
+
+extern "C" int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, const void* dy, const void* w_dgrad,
+                                void* dx, void* stream) {
+  if (g && g->Cin % 16) return DG_ERR_BAD_SHAPE;  // dx channels are a GEMM N dimension
+  dg_gg_desc d[4];
+  int n = dg_conv3x3_plan(g, 1, d);
+  if (n < 0) return n;
+  for (int i = 0; i < n; ++i) {
+    int rc = dg_gather_gemm(&d[i], ep, dy, w_dgrad, dx, stream);
+    if (rc) return rc;
+  }
+  return DG_OK;
+}

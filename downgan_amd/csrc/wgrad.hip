@@ -1,0 +1,220 @@
+// Conv 3x3 weight gradient (and the GP double-backward term): dw[co][tap][ci] += sum_p u[p,co] * x[src(p,tap),ci]
+//
+// GEMM view: M = Cout, N = Cin (one tap per workgroup), K = output pixels (N*Ho*Wo, up to 33 M at
+// cfg2) split over workgroups; partial tiles are accumulated into the fp32 gradient with
+// global_atomic_add_f32.  Both operands are "K-major" in NHWC memory (pixel index is the slow
+// dimension), so tiles are staged as [pixel][channel] in LDS (coalesced 16-B loads along channels)
+// and fragments are read TRANSPOSED:
+//   bf16 : ds_read_b64_tr_b16 (hardware 4x16 transpose) feeding v_mfma_f32_32x32x16_bf16
+//   fp32 : ds_read_b32 (one k per lane, conflict-free rows) feeding v_mfma_f32_32x32x2_f32
+// The 32x32 shapes put 32 consecutive ci on the lanes of one accumulator register, so every atomic
+// wave-instruction adds two full 128-B row segments (the full-rate shape for float atomics).
+#include "dg_internal.h"
+
+struct WGArgs {
+  const void* x; const void* u; float* dw;
+  long long ldx, ldu;
+  int H, W, Ho, Wo, stride, Cin, Cout;
+  int u_ps, cps_chunks;
+  int Mpix, ppb;
+  int nci_t;
+};
+
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+template <typename T, int BCO, int BCI>
+__global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int KP = 32;                         // pixels per K-step
+  constexpr int CPRU = BCO / EPC, CPRX = BCI / EPC;
+  constexpr int NU = KP * CPRU / 256, NX = KP * CPRX / 256;   // 16-B chunks per thread
+  static_assert(NU >= 1 && NX >= 1, "tile too small");
+  constexpr int FA = BCO / 64, FB = BCI / 64;    // 32x32 fragments per wave (2x2 waves)
+  __shared__ __attribute__((aligned(16))) T smem[2 * KP * (BCO + BCI)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx = blockIdx.x;
+  const int ci_t = bx % a.nci_t;
+  const int tap = (bx / a.nci_t) % 9;
+  const int co_t = bx / (a.nci_t * 9);
+  const int co0 = co_t * BCO, ci0 = ci_t * BCI;
+  const int dr = tap / 3 - 1, dc = tap % 3 - 1;
+  const int pbeg = blockIdx.y * a.ppb;
+  const int pend = min(a.Mpix, pbeg + a.ppb);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ U = reinterpret_cast<const T*>(a.u);
+
+  uint4 ru[NU], rx[NX];
+  auto gload = [&](int pb) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int e = tid + 256 * i, row = e / CPRU, col = e % CPRU;
+      const int p = pb + row, co = co0 + col * EPC;
+      bool ok = p < pend && co < a.Cout;
+      long long off;
+      if (!a.u_ps) off = (long long)p * a.ldu + co;
+      else {
+        const int wo = p % a.Wo, t = p / a.Wo, ho = t % a.Ho, n = t / a.Ho;
+        const int cchunk = co / EPC, q = cchunk / a.cps_chunks, c = cchunk - q * a.cps_chunks;
+        off = (((long long)(n * 2 * a.Ho + 2 * ho + (q >> 1))) * (2 * a.Wo) + 2 * wo + (q & 1)) * a.ldu + c * EPC;
+      }
+      uint4 v = *reinterpret_cast<const uint4*>(U + (ok ? off : 0ll));
+      ru[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 256 * i, row = e / CPRX, col = e % CPRX;
+      const int p = pb + row, ci = ci0 + col * EPC;
+      const int wo = p % a.Wo, t = p / a.Wo, ho = t % a.Ho, n = t / a.Ho;
+      const int hi = ho * a.stride + dr, wi = wo * a.stride + dc;
+      const bool ok = p < pend && ci < a.Cin && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const long long off = ((long long)(n * a.H + hi) * a.W + wi) * a.ldx + ci;
+      uint4 v = *reinterpret_cast<const uint4*>(X + (ok ? off : 0ll));
+      rx[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+  };
+  auto lstore = [&](int buf) {
+    T* su = smem + buf * KP * (BCO + BCI);
+    T* sx = su + KP * BCO;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int e = tid + 256 * i, row = e / CPRU, col = e % CPRU;
+      *reinterpret_cast<uint4*>(su + row * BCO + col * EPC) = ru[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 256 * i, row = e / CPRX, col = e % CPRX;
+      *reinterpret_cast<uint4*>(sx + row * BCI + col * EPC) = rx[i];
+    }
+  };
+
+  f32x16_t acc[FA][FB];
+#pragma unroll
+  for (int i = 0; i < FA; ++i)
+#pragma unroll
+    for (int j = 0; j < FB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wco = wave & 1, wci = wave >> 1;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int nsteps = (pend - pbeg + KP - 1) / KP;
+  if (nsteps <= 0) return;
+
+  gload(pbeg);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int ks = 0; ks < nsteps; ++ks) {
+    const bool more = ks + 1 < nsteps;
+    if (more) gload(pbeg + (ks + 1) * KP);
+    const T* su = smem + cur * KP * (BCO + BCI);
+    const T* sx = su + KP * BCO;
+    if constexpr (sizeof(T) == 2) {
+      // lane -> (row q of a 4x16 block, column group pp) address for the transposed read
+      const int grp16 = (lane >> 4) & 1, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+      for (int kk = 0; kk < KP / 16; ++kk) {
+        bf16x8_t fa[FA], fb[FB];
+#pragma unroll
+        for (int f = 0; f < FA; ++f) {
+          const int ch = wco * (BCO / 2) + 32 * f + 16 * grp16 + 4 * pp;
+          const int k0 = kk * 16 + 8 * h + q;
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + k0 * BCO + ch));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + (k0 + 4) * BCO + ch));
+          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+          s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          fa[f] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int f = 0; f < FB; ++f) {
+          const int ch = wci * (BCI / 2) + 32 * f + 16 * grp16 + 4 * pp;
+          const int k0 = kk * 16 + 8 * h + q;
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + k0 * BCI + ch));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + (k0 + 4) * BCI + ch));
+          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+          s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          fb[f] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+          for (int j = 0; j < FB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int k = 0; k < KP; k += 2) {
+        float fa[FA], fb[FB];
+#pragma unroll
+        for (int f = 0; f < FA; ++f) fa[f] = su[(k + h) * BCO + wco * (BCO / 2) + 32 * f + r32];
+#pragma unroll
+        for (int f = 0; f < FB; ++f) fb[f] = sx[(k + h) * BCI + wci * (BCI / 2) + 32 * f + r32];
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+          for (int j = 0; j < FB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // D[row = co][col = ci]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const long long ldw = 9ll * a.Cin;
+#pragma unroll
+  for (int i = 0; i < FA; ++i)
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+      const int ci = ci0 + wci * (BCI / 2) + 32 * j + r32;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int co = co0 + wco * (BCO / 2) + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (long long)co * ldw + tap * a.Cin + ci, acc[i][j][reg]);
+      }
+    }
+}
+
+template <typename T>
+static int wg_launch(WGArgs& a, hipStream_t st) {
+  const bool big_co = a.Cout > 64, big_ci = a.Cin > 64;
+  const int bco = big_co ? 128 : 64, bci = big_ci ? 128 : 64;
+  const int nco_t = (a.Cout + bco - 1) / bco;
+  a.nci_t = (a.Cin + bci - 1) / bci;
+  const int ntiles = nco_t * 9 * a.nci_t;
+  int splits = (2048 + ntiles - 1) / ntiles;
+  const int max_splits = (a.Mpix + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.ppb = ((a.Mpix + splits - 1) / splits + 31) / 32 * 32;
+  splits = (a.Mpix + a.ppb - 1) / a.ppb;
+  dim3 grid(ntiles, splits);
+  if (big_co && big_ci) hipLaunchKernelGGL((wg_kernel<T, 128, 128>), grid, dim3(256), 0, st, a);
+  else if (big_co) hipLaunchKernelGGL((wg_kernel<T, 128, 64>), grid, dim3(256), 0, st, a);
+  else if (big_ci) hipLaunchKernelGGL((wg_kernel<T, 64, 128>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wg_kernel<T, 64, 64>), grid, dim3(256), 0, st, a);
+  return dg_check_launch();
+}
+
+extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void* dy, float* dw, void* stream) {
+  if (!g || !x || !dy || !dw) return DG_ERR_BAD_ARG;
+  if (g->dtype != DG_F32 && g->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  if (g->N <= 0 || g->H <= 0 || g->W <= 0 || (g->stride != 1 && g->stride != 2)) return DG_ERR_BAD_SHAPE;
+  if (g->stride == 2 && ((g->H | g->W) & 1)) return DG_ERR_BAD_SHAPE;
+  if (g->Cin % 8 || g->Cout % 16 || g->Cin <= 0 || g->Cout <= 0) return DG_ERR_BAD_SHAPE;
+  if (g->pixel_shuffle && (g->stride != 1 || (g->Cout / 4) % 16)) return DG_ERR_BAD_SHAPE;
+  const int epc = g->dtype == DG_F32 ? 4 : 8;
+  if (g->ldx % epc || g->ldy % epc) return DG_ERR_BAD_SHAPE;
+  WGArgs a{};
+  a.x = x; a.u = dy; a.dw = dw; a.ldx = g->ldx; a.ldu = g->ldy;
+  a.H = g->H; a.W = g->W; a.stride = g->stride; a.Ho = g->H / g->stride; a.Wo = g->W / g->stride;
+  a.Cin = g->Cin; a.Cout = g->Cout;
+  a.u_ps = g->pixel_shuffle; a.cps_chunks = g->pixel_shuffle ? g->Cout / 4 / epc : 1;
+  const long long mp = (long long)g->N * a.Ho * a.Wo;
+  if (mp >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
+  a.Mpix = (int)mp;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return g->dtype == DG_F32 ? wg_launch<float>(a, st) : wg_launch<bf16_t>(a, st);
+}

@@ -1,0 +1,591 @@
+"""The native train-step engine: generator, critic, gradient penalty and Adam as explicit kernel chains.
+
+No autograd graph is built.  Forward, backward and the gradient-penalty double backward are written
+out as sequences of ops of ``downgan_amd.ops`` (HIP kernels through the C ABI); every buffer is
+pre-allocated once ("caller owns memory").  The maths follows the reference:
+
+* Generator  — reference DoWnGAN/networks/generator.py:14-90.  Each DenseResidualBlock keeps one
+  NHWC slab of 5F channels [x | b1 | b2 | b3 | b4]; conv k reads the first k*F channels and writes
+  its output at channel offset k*F, which removes every ``torch.cat`` (generator.py:38-40).  The
+  residuals ``out*0.2 + x`` (:41, :53) and the trunk skip (:87) are conv epilogues; PixelShuffle
+  (:73) is folded into the store addresses of the up-sampling convs.
+* Critic     — reference DoWnGAN/networks/critic.py:20-106; LeakyReLU(0.2) fused into the convs,
+  NCHW flatten (:103) absorbed by a one-time column permutation of FC1.
+* Critic step / GP / generator step — reference DoWnGAN/GAN/wasserstein.py:27-117, see
+  ``TrainEngine``.
+
+LeakyReLU'(z) is recovered from the saved activation (sign(phi(z)) == sign(z)), so no masks are stored.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import torch
+
+from . import layout
+from .ops import Conv
+
+G_SLOPE = 0.01   # nn.LeakyReLU() default, generator.py:26,72,79
+C_SLOPE = 0.2    # critic.py:24...
+RES_SCALE = 0.2  # generator.py:19,45
+FC_HID = 100     # critic.py:96
+FC_HID_P = 112   # rows of the packed FC1 weight (7 MFMA fragments)
+FC_HID_LD = 128  # row stride of the hidden activations / K of FC2
+FC_OUT_P = 16
+
+
+@dataclasses.dataclass
+class HyperParams:
+    """reference DoWnGAN/config/hyperparams.py:16-22 and GAN/stage.py:63-64."""
+    gp_lambda: float = 10.0
+    critic_iterations: int = 5
+    batch_size: int = 32
+    gamma: float = 0.01
+    content_lambda: float = 5.0
+    lr: float = 0.00025
+    beta1: float = 0.9
+    beta2: float = 0.99
+    eps: float = 1e-8
+
+
+class ParamStore:
+    """All parameters of one network in ONE flat fp32 buffer (+ grads, Adam moments, compute-precision
+    shadow and data-gradient weight packs), so Adam and the RCCL all-reduce are single flat passes."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.entries = {}      # name -> (offset, numel, shape)
+        self.size = 0
+        self.conv_dgrad = {}   # name -> (cout_p, cin_p)
+
+    def add(self, name, shape):
+        n = int(math.prod(shape))
+        assert n % 4 == 0, (name, shape)
+        self.entries[name] = (self.size, n, tuple(shape))
+        self.size += n
+
+    def finalize(self):
+        o = self.ops
+        self.p = o.zeros(self.size, dtype=torch.float32)
+        self.g = o.zeros(self.size, dtype=torch.float32)
+        self.m = o.zeros(self.size, dtype=torch.float32)
+        self.v = o.zeros(self.size, dtype=torch.float32)
+        self.shadow = self.p if o.tdtype == torch.float32 else o.zeros(self.size)
+        self.dgrad_pack = {k: o.zeros(co * 9 * ci) for k, (co, ci) in self.conv_dgrad.items()}
+        self.t = 0
+
+    def view(self, buf, name):
+        off, n, shape = self.entries[name]
+        return buf[off:off + n].view(shape)
+
+    def master(self, name):
+        return self.view(self.p, name)
+
+    def grad(self, name):
+        return self.view(self.g, name)
+
+    def w(self, name):
+        """compute-precision forward pack (flat)"""
+        off, n, _ = self.entries[name]
+        return self.shadow[off:off + n]
+
+    def w2d(self, name):
+        return self.view(self.shadow, name)
+
+    def wd(self, name):
+        return self.dgrad_pack[name]
+
+    def refresh(self, shadow_done=False):
+        """Re-derive the compute-precision packs from the fp32 master (after load / Adam)."""
+        o = self.ops
+        if o.tdtype != torch.float32 and not shadow_done:
+            o.cast(self.p, self.shadow)
+        for name, (co, ci) in self.conv_dgrad.items():
+            o.repack(self.master(name).reshape(-1), self.dgrad_pack[name], co, ci, 1)
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def adam_step(self, hp: HyperParams, grad_scale=1.0):
+        self.t += 1
+        o = self.ops
+        o.adam(self.p, self.g, self.m, self.v, None if o.tdtype == torch.float32 else self.shadow,
+               hp.lr, hp.beta1, hp.beta2, hp.eps, self.t, grad_scale)
+        self.refresh(shadow_done=True)
+
+    def load_host(self, packed: dict):
+        """packed: name -> CPU fp32 tensor of the entry's shape."""
+        host = torch.zeros(self.size, dtype=torch.float32)
+        for name, t in packed.items():
+            off, n, shape = self.entries[name]
+            assert tuple(t.shape) == shape, (name, t.shape, shape)
+            host[off:off + n] = t.reshape(-1)
+        self.p.copy_(host)
+        self.refresh()
+
+    def to_host(self, buf=None):
+        h = (self.p if buf is None else buf).detach().cpu()
+        return {name: h[off:off + n].view(shape).clone() for name, (off, n, shape) in self.entries.items()}
+
+
+# =============================================================================================== critic
+class NativeCritic:
+    """reference DoWnGAN/networks/critic.py:9-106 (Critic(coarse_dim, fine_dim, nc))."""
+
+    STRIDES = (1, 2, 1, 2, 1, 2, 1, 2)
+
+    def __init__(self, ops, coarse_dim, fine_dim, nc, batch):
+        assert fine_dim % 16 == 0, "critic.py:95 needs fine_dim divisible by 16"
+        self.ops, self.B = ops, batch
+        self.cd, self.fine, self.nc = coarse_dim, fine_dim, nc
+        cd = coarse_dim
+        self.c_real = [nc, cd, cd, 2 * cd, 2 * cd, 4 * cd, 4 * cd, 8 * cd, 8 * cd]
+        self.c_pad = [layout.pad16(c) for c in self.c_real]
+        self.convs = []
+        h = fine_dim
+        for l, st in enumerate(self.STRIDES):
+            self.convs.append(Conv(batch, h, h, self.c_pad[l], self.c_pad[l + 1], st, False))
+            h //= st
+        self.hf = h
+        self.fc_k = h * h * self.c_pad[8]
+        P = self.P = ParamStore(ops)
+        for l, cv in enumerate(self.convs):
+            P.add(f"features.{2 * l}.weight", (cv.Cout, 9, cv.Cin))
+            P.conv_dgrad[f"features.{2 * l}.weight"] = (cv.Cout, cv.Cin)
+        P.add("features.0.bias", (self.c_pad[1],))
+        P.add("classifier.0.weight", (FC_HID_P, self.fc_k))
+        P.add("classifier.0.bias", (FC_HID_LD,))
+        P.add("classifier.2.weight", (FC_OUT_P, FC_HID_LD))
+        P.add("classifier.2.bias", (FC_OUT_P,))
+        P.finalize()
+        # activations / adjoints / tangents
+        o = ops
+        self.acts = [o.zeros(*o.out_shape(cv)) for cv in self.convs]
+        self.us = [o.zeros(*o.out_shape(cv)) for cv in self.convs]
+        self.h1pre = o.zeros(batch, FC_HID_LD, dtype=torch.float32)
+        self.h1 = o.zeros(batch, FC_HID_LD)
+        self.outpre = o.zeros(batch, FC_OUT_P, dtype=torch.float32)
+        self.out = o.zeros(batch, FC_OUT_P, dtype=torch.float32)
+        self.dout = o.zeros(batch, FC_OUT_P, dtype=torch.float32)
+        self.uh1 = o.zeros(batch, FC_HID_LD, dtype=torch.float32)
+        self._tan = None
+
+    # ---- state_dict interchange (reference key names / OIHW) -------------------------------------
+    def load_state_dict(self, sd):
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32).cpu()
+        packed = {}
+        for l, cv in enumerate(self.convs):
+            packed[f"features.{2 * l}.weight"] = layout.pack_conv_weight(t(sd[f"features.{2 * l}.weight"]), cv.Cout, cv.Cin)
+        packed["features.0.bias"] = layout.pack_bias(t(sd["features.0.bias"]), self.c_pad[1])
+        packed["classifier.0.weight"] = layout.pack_fc1_weight(t(sd["classifier.0.weight"]), self.c_real[8], self.c_pad[8],
+                                                              self.hf, self.hf, FC_HID_P)
+        b1 = torch.zeros(FC_HID_LD); b1[:FC_HID] = t(sd["classifier.0.bias"])
+        packed["classifier.0.bias"] = b1
+        w2 = torch.zeros(FC_OUT_P, FC_HID_LD); w2[0, :FC_HID] = t(sd["classifier.2.weight"])[0]
+        packed["classifier.2.weight"] = w2
+        b2 = torch.zeros(FC_OUT_P); b2[0] = t(sd["classifier.2.bias"])[0]
+        packed["classifier.2.bias"] = b2
+        self.P.load_host(packed)
+
+    def unpack(self, host):
+        """packed host dict (params or grads) -> reference-shaped dict."""
+        sd = {}
+        for l in range(8):
+            sd[f"features.{2 * l}.weight"] = layout.unpack_conv_weight(host[f"features.{2 * l}.weight"], self.c_real[l + 1], self.c_real[l])
+        sd["features.0.bias"] = layout.unpack_bias(host["features.0.bias"], self.c_real[1])
+        sd["classifier.0.weight"] = layout.unpack_fc1_weight(host["classifier.0.weight"], FC_HID, self.c_real[8], self.c_pad[8], self.hf, self.hf)
+        sd["classifier.0.bias"] = host["classifier.0.bias"][:FC_HID].clone()
+        sd["classifier.2.weight"] = host["classifier.2.weight"][:1, :FC_HID].clone()
+        sd["classifier.2.bias"] = host["classifier.2.bias"][:1].clone()
+        return sd
+
+    def state_dict(self):
+        return self.unpack(self.P.to_host())
+
+    def grad_dict(self):
+        return self.unpack(self.P.to_host(self.P.g))
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def forward(self, x):
+        """critic.py:101-106.  x: NHWC [B, fine, fine, c_pad[0]].  Returns out[:, 0] (fp32 view)."""
+        o, P = self.ops, self.P
+        cur = x
+        for l, cv in enumerate(self.convs):
+            o.conv_fwd(cv, cur, P.w(f"features.{2 * l}.weight"), self.acts[l],
+                       bias=P.master("features.0.bias") if l == 0 else None, act=C_SLOPE)
+            cur = self.acts[l]
+        y7 = self.acts[7].view(self.B, self.fc_k)
+        self.h1pre.zero_()
+        o.linear_fwd(y7, P.w2d("classifier.0.weight"), self.h1pre)
+        o.bias_act(self.h1pre, P.master("classifier.0.bias"), self.h1, act=C_SLOPE)
+        self.outpre.zero_()
+        o.linear_fwd(self.h1, P.w2d("classifier.2.weight"), self.outpre)
+        o.bias_act(self.outpre, P.master("classifier.2.bias"), self.out)
+        return self.out
+
+    # ---- adjoint chain (backward of a forward just run on x) ---------------------------------------
+    def backward(self, x, dout_value, wgrad=True, dx=None):
+        """d(out_b)/d(.) * dout_value for every sample.  wgrad: accumulate parameter gradients
+        (autograd backward of wasserstein.py:52); dx: if given, receives the input gradient
+        (wasserstein.py:100-106 / :80)."""
+        o, P = self.ops, self.P
+        self.dout.zero_()
+        o.fill_col(self.dout, 0, dout_value)
+        y7 = self.acts[7].view(self.B, self.fc_k)
+        if wgrad:
+            o.linear_dw(self.dout, self.h1, P.grad("classifier.2.weight"))
+            o.colsum(self.dout, P.grad("classifier.2.bias"))
+        o.linear_dx(self.dout, P.w2d("classifier.2.weight"), self.uh1, mask=self.h1, mask_slope=C_SLOPE)
+        if wgrad:
+            o.linear_dw(self.uh1[:, :FC_HID_P], y7, P.grad("classifier.0.weight"))
+            o.colsum(self.uh1, P.grad("classifier.0.bias"))
+        o.linear_dx(self.uh1[:, :FC_HID_P], P.w2d("classifier.0.weight"), self.us[7].view(self.B, self.fc_k),
+                    mask=y7, mask_slope=C_SLOPE)
+        for l in range(7, -1, -1):
+            cv = self.convs[l]
+            name = f"features.{2 * l}.weight"
+            xin = self.acts[l - 1] if l > 0 else x
+            if wgrad:
+                o.conv_wgrad(cv, xin, self.us[l], P.grad(name).reshape(-1))
+                if l == 0:
+                    o.colsum(self.us[0], P.grad("features.0.bias"))
+            if l > 0:
+                o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask=self.acts[l - 1], mask_slope=C_SLOPE)
+            elif dx is not None:
+                o.conv_dgrad(cv, self.us[0], P.wd(name), dx)
+
+    # ---- gradient penalty: forward, adjoint, norm, tangent forward + weight gradients -------------
+    def gp_pass(self, xhat, g_buf, v_buf, ss, coef, gp_scalar, hp: HyperParams, b_global):
+        """wasserstein.py:87-117 and its contribution to critic_loss.backward (:52).
+
+        g = d sum_b C(xhat_b) / d xhat (adjoint chain with grad_outputs = 1).  With piecewise-linear
+        activations the penalty's parameter gradient is  sum_l wgrad(tangent_{l-1}, adjoint_l)  where
+        the tangent is v0 = dGP/dg pushed forward through the same masked linear maps."""
+        o, P = self.ops, self.P
+        self.forward(xhat)
+        self.backward(xhat, 1.0, wgrad=False, dx=g_buf)
+        ss.zero_()
+        o.sumsq_rows(g_buf, ss)
+        o.gp_finish(ss, self.B, b_global, hp.gp_lambda, hp.gp_lambda, coef, gp_scalar)
+        o.scale_rows(g_buf, coef, v_buf)
+        if self._tan is None:
+            big = max(a.numel() for a in self.acts)
+            self._tan = [o.zeros(big), o.zeros(big)]
+            self._th1pre = o.zeros(self.B, FC_HID_LD, dtype=torch.float32)
+            self._th1 = o.zeros(self.B, FC_HID_LD)
+            self._ones = o.zeros(self.B, FC_OUT_P, dtype=torch.float32)
+            o.fill_col(self._ones, 0, 1.0)
+        t = v_buf
+        for l, cv in enumerate(self.convs):
+            name = f"features.{2 * l}.weight"
+            o.conv_wgrad(cv, t, self.us[l], P.grad(name).reshape(-1))
+            tn = self._tan[l & 1][:self.acts[l].numel()].view(self.acts[l].shape)
+            o.conv_fwd(cv, t, P.w(name), tn, mask=self.acts[l], mask_slope=C_SLOPE)
+            t = tn
+        t7 = t.view(self.B, self.fc_k)
+        o.linear_dw(self.uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"))
+        self._th1pre.zero_()
+        o.linear_fwd(t7, P.w2d("classifier.0.weight"), self._th1pre)
+        o.bias_act(self._th1pre, None, self._th1, mask=self.h1, mask_slope=C_SLOPE)
+        o.linear_dw(self._ones, self._th1, P.grad("classifier.2.weight"))
+
+
+# =============================================================================================== generator
+class NativeGenerator:
+    """reference DoWnGAN/networks/generator.py:56-90
+    (Generator(filters, fine_dims, channels, n_predictands=2, num_res_blocks=16, num_upsample=3))."""
+
+    def __init__(self, ops, filters, channels, batch, coarse_side, n_predictands=2, num_res_blocks=16, num_upsample=3):
+        assert filters % 16 == 0, "native path needs filters to be a multiple of 16"
+        self.ops, self.B, self.S = ops, batch, coarse_side
+        self.F, self.cin, self.npred = filters, channels, n_predictands
+        self.cin_p, self.np_p = layout.pad16(channels), layout.pad16(n_predictands)
+        self.nrb, self.nup = num_res_blocks, num_upsample
+        F_, S, B = filters, coarse_side, batch
+        self.cv_conv1 = Conv(B, S, S, self.cin_p, F_)
+        self.cv_b = [Conv(B, S, S, k * F_, F_) for k in range(1, 6)]
+        self.cv_conv2 = Conv(B, S, S, F_, F_)
+        self.cv_up = [Conv(B, S << u, S << u, F_, 4 * F_, 1, True) for u in range(num_upsample)]
+        hs = S << num_upsample
+        self.cv_c30 = Conv(B, hs, hs, F_, F_)
+        self.cv_c32 = Conv(B, hs, hs, F_, self.np_p)
+        P = self.P = ParamStore(ops)
+
+        def addconv(name, cv, dgrad=True):
+            P.add(name + ".weight", (cv.Cout, 9, cv.Cin))
+            P.add(name + ".bias", (cv.Cout,))
+            if dgrad:
+                P.conv_dgrad[name + ".weight"] = (cv.Cout, cv.Cin)
+        addconv("conv1", self.cv_conv1, dgrad=False)
+        for i in range(num_res_blocks):
+            for j in range(3):
+                for k in range(1, 6):
+                    addconv(f"res_blocks.{i}.dense_blocks.{j}.b{k}.0", self.cv_b[k - 1])
+        addconv("conv2", self.cv_conv2)
+        for u in range(num_upsample):
+            addconv(f"upsampling.{3 * u}", self.cv_up[u])
+        addconv("conv3.0", self.cv_c30)
+        addconv("conv3.2", self.cv_c32)
+        P.finalize()
+        o = ops
+        self.ndrb = 3 * num_res_blocks
+        self.out1 = o.zeros(B, S, S, F_)
+        self.trunk = o.zeros(B, S, S, F_)
+        self.ups = [o.zeros(B, S << (u + 1), S << (u + 1), F_) for u in range(num_upsample)]
+        self.c30 = o.zeros(B, hs, hs, F_)
+        self.fake = o.zeros(B, hs, hs, self.np_p)
+        self._ring = [o.zeros(B, S, S, 5 * F_) for _ in range(4)]
+        self._saved = None
+        self._bwd = None
+
+    # ---- state_dict interchange ------------------------------------------------------------------
+    def _conv_names(self):
+        yield "conv1", self.cv_conv1, self.cin, self.F
+        for i in range(self.nrb):
+            for j in range(3):
+                for k in range(1, 6):
+                    yield f"res_blocks.{i}.dense_blocks.{j}.b{k}.0", self.cv_b[k - 1], k * self.F, self.F
+        yield "conv2", self.cv_conv2, self.F, self.F
+        for u in range(self.nup):
+            yield f"upsampling.{3 * u}", self.cv_up[u], self.F, 4 * self.F
+        yield "conv3.0", self.cv_c30, self.F, self.F
+        yield "conv3.2", self.cv_c32, self.F, self.npred
+
+    def load_state_dict(self, sd):
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32).cpu()
+        packed = {}
+        for name, cv, ci, co in self._conv_names():
+            packed[name + ".weight"] = layout.pack_conv_weight(t(sd[name + ".weight"]), cv.Cout, cv.Cin, cv.pixel_shuffle)
+            packed[name + ".bias"] = layout.pack_bias(t(sd[name + ".bias"]), cv.Cout, cv.pixel_shuffle)
+        self.P.load_host(packed)
+
+    def unpack(self, host):
+        sd = {}
+        for name, cv, ci, co in self._conv_names():
+            sd[name + ".weight"] = layout.unpack_conv_weight(host[name + ".weight"], co, ci, cv.pixel_shuffle)
+            sd[name + ".bias"] = layout.unpack_bias(host[name + ".bias"], co, cv.pixel_shuffle)
+        return sd
+
+    def state_dict(self):
+        return self.unpack(self.P.to_host())
+
+    def grad_dict(self):
+        return self.unpack(self.P.to_host(self.P.g))
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def _slab(self, d, save):
+        if save:
+            if self._saved is None:
+                o = self.ops
+                self._saved = [o.zeros(self.B, self.S, self.S, 5 * self.F) for _ in range(self.ndrb)]
+                self._saved.append(o.zeros(self.B, self.S, self.S, self.F))
+            return self._saved[d]
+        return self._ring[d % 4]
+
+    def forward(self, x, save=False):
+        """generator.py:83-90.  x: NHWC [B,S,S,cin_p].  save=True keeps every dense-block slab for backward."""
+        o, P, F_ = self.ops, self.P, self.F
+        W = lambda n: P.w(n + ".weight")
+        Bz = lambda n: P.master(n + ".bias")
+        o.conv_fwd(self.cv_conv1, x, W("conv1"), self.out1, bias=Bz("conv1"))
+        o.axpby(self._slab(0, save)[..., :F_], self.out1)
+        for i in range(self.nrb):
+            rrdb_in = self._slab(3 * i, save)[..., :F_]
+            for j in range(3):
+                d = 3 * i + j
+                slab, nxt = self._slab(d, save), self._slab(d + 1, save)
+                pre = f"res_blocks.{i}.dense_blocks.{j}.b"
+                for k in range(1, 5):
+                    o.conv_fwd(self.cv_b[k - 1], slab[..., :k * F_], W(f"{pre}{k}.0"), slab[..., k * F_:(k + 1) * F_],
+                               bias=Bz(f"{pre}{k}.0"), act=G_SLOPE)
+                ep = dict(bias=Bz(f"{pre}5.0"), r1=slab[..., :F_], s1=RES_SCALE)          # generator.py:41
+                if j == 2:
+                    ep.update(r2=rrdb_in, s2=RES_SCALE)                                  # generator.py:53
+                o.conv_fwd(self.cv_b[4], slab, W(f"{pre}5.0"), nxt[..., :F_], **ep)
+        o.conv_fwd(self.cv_conv2, self._slab(self.ndrb, save)[..., :F_], W("conv2"), self.trunk, bias=Bz("conv2"),
+                   r1=self.out1, s1=1.0)                                                 # generator.py:86-87
+        cur = self.trunk
+        for u in range(self.nup):
+            o.conv_fwd(self.cv_up[u], cur, W(f"upsampling.{3 * u}"), self.ups[u], bias=Bz(f"upsampling.{3 * u}"), act=G_SLOPE)
+            cur = self.ups[u]
+        o.conv_fwd(self.cv_c30, cur, W("conv3.0"), self.c30, bias=Bz("conv3.0"), act=G_SLOPE)
+        o.conv_fwd(self.cv_c32, self.c30, W("conv3.2"), self.fake, bias=Bz("conv3.2"))
+        return self.fake
+
+    # ---- backward (after forward(save=True)) ---------------------------------------------------------
+    def backward(self, x, dfake):
+        """Parameter gradients of the generator for d loss / d fake = dfake (autograd backward of
+        wasserstein.py:80 through generator.py:83-90)."""
+        o, P, F_, B, S = self.ops, self.P, self.F, self.B, self.S
+        if self._bwd is None:
+            hs = S << self.nup
+            self._bwd = dict(
+                d_c30=o.zeros(B, hs, hs, F_), d_ups=[o.zeros(B, S << (u + 1), S << (u + 1), F_) for u in range(self.nup)],
+                d_trunk=o.zeros(B, S, S, F_), gy=[o.zeros(B, S, S, F_), o.zeros(B, S, S, F_)], go=o.zeros(B, S, S, F_),
+                d5=o.zeros(B, S, S, F_), gslab=[o.zeros(B, S, S, 5 * F_), o.zeros(B, S, S, 5 * F_)])
+        bw = self._bwd
+        W = lambda n: P.w(n + ".weight")
+        WD = lambda n: P.wd(n + ".weight")
+        GW = lambda n: P.grad(n + ".weight").reshape(-1)
+        GB = lambda n: P.grad(n + ".bias")
+        # conv3.2 / conv3.0
+        o.conv_wgrad(self.cv_c32, self.c30, dfake, GW("conv3.2")); o.colsum(dfake, GB("conv3.2"))
+        o.conv_dgrad(self.cv_c32, dfake, WD("conv3.2"), bw["d_c30"], mask=self.c30, mask_slope=G_SLOPE)
+        top = self.ups[-1] if self.nup else self.trunk
+        o.conv_wgrad(self.cv_c30, top, bw["d_c30"], GW("conv3.0")); o.colsum(bw["d_c30"], GB("conv3.0"))
+        dcur = bw["d_ups"][-1] if self.nup else bw["d_trunk"]
+        if self.nup:
+            o.conv_dgrad(self.cv_c30, bw["d_c30"], WD("conv3.0"), dcur, mask=self.ups[-1], mask_slope=G_SLOPE)
+        else:
+            o.conv_dgrad(self.cv_c30, bw["d_c30"], WD("conv3.0"), dcur)
+        # up-sampling convs (activation before the shuffle: the mask commutes with the permutation)
+        for u in range(self.nup - 1, -1, -1):
+            name = f"upsampling.{3 * u}"
+            xin = self.ups[u - 1] if u > 0 else self.trunk
+            o.conv_wgrad(self.cv_up[u], xin, dcur, GW(name)); o.colsum_ps(dcur, GB(name))
+            if u > 0:
+                o.conv_dgrad(self.cv_up[u], dcur, WD(name), bw["d_ups"][u - 1], mask=self.ups[u - 1], mask_slope=G_SLOPE)
+                dcur = bw["d_ups"][u - 1]
+            else:
+                o.conv_dgrad(self.cv_up[u], dcur, WD(name), bw["d_trunk"])
+                dcur = bw["d_trunk"]
+        d_trunk = dcur                                   # = d out1 (skip) = d out2
+        # conv2
+        o.conv_wgrad(self.cv_conv2, self._saved[self.ndrb][..., :F_], d_trunk, GW("conv2")); o.colsum(d_trunk, GB("conv2"))
+        gy = bw["gy"][0]
+        o.conv_dgrad(self.cv_conv2, d_trunk, WD("conv2"), gy)
+        gyi = 0
+        for i in range(self.nrb - 1, -1, -1):
+            # RRDB i: y = 0.2*o_{3i+2} + x_rrdb
+            go = bw["go"]
+            o.axpby(go, gy, RES_SCALE)                    # d o_{3i+2}
+            for j in (2, 1, 0):
+                d = 3 * i + j
+                slab, gs = self._saved[d], bw["gslab"][d & 1]
+                pre = f"res_blocks.{i}.dense_blocks.{j}.b"
+                o.axpby(bw["d5"], go, RES_SCALE)          # d b5-out = 0.2 * d o
+                o.conv_wgrad(self.cv_b[4], slab, bw["d5"], GW(f"{pre}5.0")); o.colsum(bw["d5"], GB(f"{pre}5.0"))
+                o.conv_dgrad(self.cv_b[4], bw["d5"], WD(f"{pre}5.0"), gs)
+                o.axpby(gs[..., :F_], gs[..., :F_], 1.0, go, 1.0)        # + identity path of o = 0.2*b5 + x
+                for k in range(4, 0, -1):
+                    uk = gs[..., k * F_:(k + 1) * F_]
+                    o.mask_mul(uk, slab[..., k * F_:(k + 1) * F_], G_SLOPE)
+                    o.conv_wgrad(self.cv_b[k - 1], slab[..., :k * F_], uk, GW(f"{pre}{k}.0")); o.colsum(uk, GB(f"{pre}{k}.0"))
+                    o.conv_dgrad(self.cv_b[k - 1], uk, WD(f"{pre}{k}.0"), gs[..., :k * F_], accumulate=True)
+                go = gs[..., :F_]                         # d x_drb = d o of the previous dense block
+            gyn = bw["gy"][gyi ^ 1]
+            o.axpby(gyn, go, 1.0, gy, 1.0)                # d x_rrdb = d x_drb(3i) + d y (identity path)
+            gy, gyi = gyn, gyi ^ 1
+        # conv1: d out1 = trunk-path gradient + skip gradient
+        o.axpby(gy, gy, 1.0, d_trunk, 1.0)
+        o.conv_wgrad(self.cv_conv1, x, gy, GW("conv1")); o.colsum(gy, GB("conv1"))
+
+
+# =============================================================================================== train step
+class TrainEngine:
+    """One WGAN-GP train step = WassersteinGAN._critic_train_iteration (+ _generator_train_iteration
+    every ``critic_iterations`` steps), reference DoWnGAN/GAN/wasserstein.py:27-83,131-147.
+
+    ``dist`` (optional) is an object with ``world_size``, ``allreduce_sum_(tensor)`` and
+    ``reduce_scalars(dict)``: every rank holds B samples of the global batch B*world; per-sample terms
+    are normalised by the global batch so the flat gradient buffers are simply summed (plain data
+    parallelism).
+    """
+
+    SCALARS = ("c_real_mean", "c_fake_mean", "gp_ret", "g_c_fake_mean", "l1_sum")
+
+    def __init__(self, ops, coarse_side, filters, channels, batch, hp: HyperParams = None, n_predictands=2,
+                 num_res_blocks=16, num_upsample=3, dist=None):
+        self.ops, self.hp = ops, hp or HyperParams()
+        self.B, self.S = batch, coarse_side
+        self.dist = dist
+        self.world = dist.world_size if dist is not None else 1
+        fine = coarse_side << num_upsample
+        self.G = NativeGenerator(ops, filters, channels, batch, coarse_side, n_predictands, num_res_blocks, num_upsample)
+        self.C = NativeCritic(ops, filters, fine, n_predictands, batch)
+        assert self.C.c_pad[0] == self.G.np_p
+        o = ops
+        self.xhat = o.zeros(batch, fine, fine, self.G.np_p)
+        self.gbuf = o.zeros(batch, fine, fine, self.G.np_p)
+        self.vbuf = o.zeros(batch, fine, fine, self.G.np_p)
+        self.dfake = None
+        self.ss = o.zeros(batch, dtype=torch.float32)
+        self.coef = o.zeros(batch, dtype=torch.float32)
+        self.scal = o.zeros(8, dtype=torch.float32)
+        self.alpha_dev = o.zeros(batch, dtype=torch.float32)
+        self.num_steps = 0
+        self.n_real_elems = batch * n_predictands * fine * fine
+
+    def _sc(self, name):
+        i = self.SCALARS.index(name)
+        return self.scal[i:i + 1]
+
+    def _allreduce_and_step(self, P):
+        # local gradients are already normalised by the GLOBAL batch, so ranks are summed, not averaged
+        if self.dist is not None and self.world > 1:
+            self.dist.allreduce_sum_(P.g)
+        P.adam_step(self.hp, 1.0)
+
+    def critic_iteration(self, coarse, fine, alpha, apply_update=True):
+        """wasserstein.py:27-55.  coarse/fine: native NHWC tensors; alpha: fp32 [B] on the device
+        (replaces torch.rand at :91).  The generator runs forward-only: its backward in the reference's
+        critic step is dead work (G grads are zeroed at :65 before any use)."""
+        o, hp, C, B = self.ops, self.hp, self.C, self.B
+        bg = B * self.world
+        fake = self.G.forward(coarse, save=False)                 # :35
+        C.P.zero_grad()                                           # :43
+        out = C.forward(fine)                                     # :37
+        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
+        C.backward(fine, -1.0 / bg)                               # d(-mean c_real)
+        out = C.forward(fake)                                     # :38
+        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
+        C.backward(fake, 1.0 / bg)                                # d(+mean c_fake)
+        o.gp_interp(fine, fake, alpha, self.xhat)                 # :94
+        C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg)   # :40,:87-117
+        if apply_update:
+            self._allreduce_and_step(C.P)                         # :52-55
+
+    def generator_iteration(self, coarse, fine, apply_update=True):
+        """wasserstein.py:58-83: g_loss = -mean(C(G(x)))*gamma + content_lambda*L1(G(x), y)."""
+        o, hp, C, G, B = self.ops, self.hp, self.C, self.G, self.B
+        bg = B * self.world
+        if self.dfake is None:
+            self.dfake = o.zeros(*self.G.fake.shape)
+        G.P.zero_grad()                                           # :65
+        fake = G.forward(coarse, save=True)                       # :67
+        out = C.forward(fake)                                     # :68
+        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("g_c_fake_mean"))
+        C.backward(fake, -hp.gamma / bg, wgrad=False, dx=self.gbuf)            # d(-gamma*mean c_fake)/d fake
+        self._sc("l1_sum").zero_()
+        o.l1(fake, fine, self._sc("l1_sum"), grad=self.dfake, grad_scale=hp.content_lambda / (self.n_real_elems * self.world),
+             addend=self.gbuf)                                    # :78 + losses.py:51-53
+        G.backward(coarse, self.dfake)                            # :80
+        if apply_update:
+            self._allreduce_and_step(G.P)                         # :83
+
+    def train_step(self, coarse, fine, alpha):
+        """loop body of _train_epoch, wasserstein.py:131-147 (metrics pass :140 excluded)."""
+        self.critic_iteration(coarse, fine, alpha)
+        ran_g = self.num_steps % self.hp.critic_iterations == 0   # :136
+        if ran_g:
+            self.generator_iteration(coarse, fine)
+        self.num_steps += 1
+        return ran_g
+
+    def read_scalars(self, ran_g=False):
+        """Synchronises and returns the scalars the reference computes and drops (:46-50, :74-78)."""
+        s = self.scal.detach().cpu().tolist()
+        hp = self.hp
+        d = dict(zip(self.SCALARS, s))
+        if self.dist is not None and self.world > 1:
+            d = self.dist.reduce_scalars(d, mean=("c_real_mean", "c_fake_mean", "g_c_fake_mean"), total=("gp_ret", "l1_sum"))
+        out = {"c_real_mean": d["c_real_mean"], "c_fake_mean": d["c_fake_mean"], "gp_ret": d["gp_ret"]}
+        out["gradient_penalty"] = hp.gp_lambda * d["gp_ret"]
+        out["critic_loss"] = d["c_fake_mean"] - d["c_real_mean"] + out["gradient_penalty"]
+        out["w_estimate"] = d["c_real_mean"] - d["c_fake_mean"]
+        if ran_g:
+            out["g_c_fake_mean"] = d["g_c_fake_mean"]
+            out["content_loss"] = d["l1_sum"] / (self.n_real_elems * self.world)
+            out["g_loss"] = -d["g_c_fake_mean"] * hp.gamma + hp.content_lambda * out["content_loss"]
+        return out

@@ -1,0 +1,291 @@
+"""Tensor-level wrappers over the C ABI (include/downgan_hip.h) — the only compute backend.
+
+Every op takes torch tensors that live on the GPU (torch is used for device memory and streams
+only), checks shapes/layouts on the host, and launches the HIP kernel on torch's current stream.
+Activations are NHWC tensors ``[N, H, W, C]`` (or channel-slice views of a wider slab) with unit
+channel stride; ``ld`` is the pixel stride in elements.
+
+There is deliberately no CPU implementation here.  ``oracle/emu_ops.py`` (test infrastructure)
+implements the same op contracts with torch-CPU so that the host-side engine logic can be tested
+without a GPU; the product never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+
+import torch
+
+from . import _lib
+from ._lib import ConvGeom, Epilogue, check
+
+TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16}
+DG_DTYPE = {"f32": _lib.DG_F32, "bf16": _lib.DG_BF16}
+
+
+@dataclasses.dataclass(frozen=True)
+class Conv:
+    """One reference nn.Conv2d(Cin, Cout, 3, stride, 1) layer in native (padded) terms."""
+    N: int
+    H: int
+    W: int
+    Cin: int          # padded
+    Cout: int         # padded
+    stride: int = 1
+    pixel_shuffle: bool = False
+
+    @property
+    def Ho(self):
+        return self.H // self.stride
+
+    @property
+    def Wo(self):
+        return self.W // self.stride
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def pix_layout(t):
+    """(ld, rows) of an NHWC tensor/view whose pixels are laid out densely with stride ld."""
+    assert t.dim() == 4 and t.stride(3) == 1, (t.shape, t.stride())
+    ld = t.stride(2)
+    n, h, w, _ = t.shape
+    assert (w == 1 or t.stride(2) == ld) and (h == 1 or t.stride(1) == w * ld) and (n == 1 or t.stride(0) == h * w * ld), \
+        (t.shape, t.stride())
+    return ld, n * h * w
+
+
+class HipOps:
+    """The HIP backend.  ``dtype`` is the storage/compute precision of activations and weight packs."""
+
+    name = "hip"
+
+    def __init__(self, dtype="bf16", device="cuda:0"):
+        assert dtype in TORCH_DTYPE
+        if not torch.cuda.is_available():
+            raise RuntimeError("downgan_amd.ops.HipOps needs a ROCm GPU (no CPU fallback exists)")
+        self.dtype = dtype
+        self.tdtype = TORCH_DTYPE[dtype]
+        self.dg = DG_DTYPE[dtype]
+        self.device = torch.device(device)
+        self.lib = _lib.lib()
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _act(self, t):
+        assert t.dtype == self.tdtype and t.is_cuda, (t.dtype, t.device)
+        return t
+
+    def _geom(self, cv: Conv, ldx, ldy):
+        return ConvGeom(dtype=self.dg, N=cv.N, H=cv.H, W=cv.W, Cin=cv.Cin, Cout=cv.Cout, stride=cv.stride,
+                        pixel_shuffle=int(cv.pixel_shuffle), ldx=ldx, ldy=ldy)
+
+    def _epilogue(self, out, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None, mask_slope=1.0,
+                  accumulate=False):
+        ep = Epilogue()
+        ep.bias = bias.data_ptr() if bias is not None else None
+        if bias is not None:
+            assert bias.dtype == torch.float32 and bias.numel() >= out.shape[-1] * (4 if False else 1)
+        ep.has_act = int(act is not None)
+        ep.act_slope = float(act) if act is not None else 1.0
+        for name, t, s in (("r1", r1, s1), ("r2", r2, s2)):
+            if t is not None:
+                self._act(t)
+                assert t.shape == out.shape, (name, t.shape, out.shape)
+                setattr(ep, name, t.data_ptr())
+                setattr(ep, "ld" + name, pix_layout(t)[0])
+            setattr(ep, "s" + name[1], float(s))
+        if mask is not None:
+            self._act(mask)
+            assert mask.shape == out.shape, (mask.shape, out.shape)
+            ep.mask = mask.data_ptr()
+            ep.ldmask = pix_layout(mask)[0]
+        ep.mask_slope = float(mask_slope)
+        ep.accumulate = int(accumulate)
+        return ep
+
+    # ------------------------------------------------------------------ conv family
+    def out_shape(self, cv: Conv):
+        if cv.pixel_shuffle:
+            return (cv.N, 2 * cv.Ho, 2 * cv.Wo, cv.Cout // 4)
+        return (cv.N, cv.Ho, cv.Wo, cv.Cout)
+
+    def conv_fwd(self, cv: Conv, x, w_fwd, y, **ep):
+        self._act(x); self._act(y); self._act(w_fwd)
+        assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin), (x.shape, cv)
+        assert tuple(y.shape) == self.out_shape(cv), (y.shape, cv)
+        assert w_fwd.numel() == cv.Cout * 9 * cv.Cin and w_fwd.is_contiguous()
+        g = self._geom(cv, pix_layout(x)[0], pix_layout(y)[0])
+        e = self._epilogue(y, **ep)
+        check(self.lib.dg_conv3x3_fwd(C.byref(g), C.byref(e), _ptr(x), _ptr(w_fwd), _ptr(y), self._stream()), "dg_conv3x3_fwd")
+
+    def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, **ep):
+        self._act(dy); self._act(dx); self._act(w_dgrad)
+        assert tuple(dx.shape) == (cv.N, cv.H, cv.W, cv.Cin), (dx.shape, cv)
+        assert tuple(dy.shape) == self.out_shape(cv), (dy.shape, cv)
+        assert w_dgrad.numel() == cv.Cout * 9 * cv.Cin and w_dgrad.is_contiguous()
+        g = self._geom(cv, pix_layout(dx)[0], pix_layout(dy)[0])
+        e = self._epilogue(dx, **ep)
+        check(self.lib.dg_conv3x3_dgrad(C.byref(g), C.byref(e), _ptr(dy), _ptr(w_dgrad), _ptr(dx), self._stream()), "dg_conv3x3_dgrad")
+
+    def conv_wgrad(self, cv: Conv, x, dy, dw):
+        self._act(x); self._act(dy)
+        assert dw.dtype == torch.float32 and dw.numel() == cv.Cout * 9 * cv.Cin and dw.is_contiguous()
+        assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin), (x.shape, cv)
+        assert tuple(dy.shape) == self.out_shape(cv), (dy.shape, cv)
+        g = self._geom(cv, pix_layout(x)[0], pix_layout(dy)[0])
+        check(self.lib.dg_conv3x3_wgrad(C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), self._stream()), "dg_conv3x3_wgrad")
+
+    def colsum(self, dy, db):
+        """db[c] += sum over all pixels/rows of dy[..., c]; dy is NHWC (any dtype of {fp32, compute}) or 2-D."""
+        assert db.dtype == torch.float32
+        dg = _lib.DG_F32 if dy.dtype == torch.float32 else self.dg
+        if dy.dim() == 2:
+            rows, ld, Cc = dy.shape[0], dy.stride(0), dy.shape[1]
+        else:
+            ld, rows = pix_layout(dy)
+            Cc = dy.shape[-1]
+        assert db.numel() >= Cc
+        check(self.lib.dg_colsum(dg, _ptr(dy), rows, ld, 1, ld, Cc, _ptr(db), self._stream()), "dg_colsum")
+
+    def colsum_ps(self, dy, db):
+        """Bias gradient of a pixel-shuffle conv: dy is stored shuffled [N,2H,2W,F]; db has 4F entries
+        ordered (2i+j)*F + c (the native packing of the conv's output channels)."""
+        self._act(dy)
+        ld, _ = pix_layout(dy)
+        n, h2, w2, f = dy.shape
+        for i in range(2):
+            for j in range(2):
+                sub = dy[:, i::2, j::2, :]
+                check(self.lib.dg_colsum(self.dg, _ptr(sub), n * (h2 // 2), 2 * w2 * ld, w2 // 2, 2 * ld, f,
+                                         _ptr(db[(2 * i + j) * f:]), self._stream()), "dg_colsum")
+
+    def repack(self, master, dst, cout, cin, kind):
+        assert master.dtype == torch.float32 and master.numel() == cout * 9 * cin
+        assert dst.dtype == self.tdtype and dst.numel() == cout * 9 * cin
+        check(self.lib.dg_repack_conv_weights(self.dg, kind, _ptr(master), _ptr(dst), cout, cin, self._stream()), "dg_repack_conv_weights")
+
+    # ------------------------------------------------------------------ linear family
+    def linear_fwd(self, x, w, y):
+        """y[B,ldy] (fp32, pre-zeroed) += x[B,K] @ w[O,K]^T"""
+        self._act(x); self._act(w)
+        B, K = x.shape
+        O = w.shape[0]
+        assert w.shape[1] == K and y.dtype == torch.float32 and y.shape[0] == B and y.shape[1] >= O
+        check(self.lib.dg_linear_fwd(self.dg, _ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(y), y.stride(0), B, O, K,
+                                     self._stream()), "dg_linear_fwd")
+
+    def linear_dx(self, dy, w, dx, mask=None, mask_slope=1.0):
+        """dx[B,K] = (dy[B,O] @ w[O,K]) * leaky'(mask)"""
+        self._act(w)
+        B, K = dx.shape
+        O = w.shape[0]
+        assert dy.dtype == torch.float32 and dy.shape[0] == B and dy.shape[1] >= O and w.shape[1] == K
+        out_dg = _lib.DG_F32 if dx.dtype == torch.float32 else self.dg
+        if mask is not None:
+            self._act(mask)
+            assert mask.shape == dx.shape
+        check(self.lib.dg_linear_dx(self.dg, out_dg, _ptr(dy), dy.stride(0), _ptr(w), w.stride(0), _ptr(dx), dx.stride(0),
+                                    _ptr(mask), mask.stride(0) if mask is not None else 0, float(mask_slope), B, O, K,
+                                    self._stream()), "dg_linear_dx")
+
+    def linear_dw(self, dy, x, dw):
+        """dw[O,K] (fp32) += dy[B,O]^T @ x[B,K]"""
+        self._act(x)
+        B, K = x.shape
+        O = dw.shape[0]
+        assert dy.dtype == torch.float32 and dy.shape[0] == B and dy.shape[1] >= O and dw.dtype == torch.float32 and dw.shape[1] == K
+        check(self.lib.dg_linear_dw(self.dg, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dw.stride(0), B, O, K,
+                                    self._stream()), "dg_linear_dw")
+
+    def bias_act(self, inp, bias, out, act=None, mask=None, mask_slope=1.0):
+        rows, Cc = out.shape
+        assert inp.dtype == torch.float32 and inp.shape[0] == rows and inp.shape[1] >= Cc
+        out_dg = _lib.DG_F32 if out.dtype == torch.float32 else self.dg
+        if mask is not None:
+            assert mask.dtype == out.dtype
+        check(self.lib.dg_bias_act(out_dg, _ptr(inp), inp.stride(0), _ptr(bias), _ptr(out), out.stride(0), rows, Cc,
+                                   int(act is not None), float(act or 1.0), _ptr(mask), mask.stride(0) if mask is not None else 0,
+                                   float(mask_slope), self._stream()), "dg_bias_act")
+
+    # ------------------------------------------------------------------ elementwise / reductions
+    def mask_mul(self, u, y, slope):
+        self._act(u); self._act(y)
+        assert u.shape == y.shape
+        ldu, rows = pix_layout(u)
+        check(self.lib.dg_mask_mul(self.dg, _ptr(u), ldu, _ptr(y), pix_layout(y)[0], rows, u.shape[-1], float(slope), self._stream()), "dg_mask_mul")
+
+    def axpby(self, out, x, a=1.0, y=None, b=0.0):
+        self._act(out); self._act(x)
+        assert out.shape == x.shape and (y is None or y.shape == x.shape)
+        ldo, rows = pix_layout(out)
+        check(self.lib.dg_axpby(self.dg, _ptr(out), ldo, _ptr(x), pix_layout(x)[0], float(a), _ptr(y),
+                                pix_layout(y)[0] if y is not None else 0, float(b), rows, x.shape[-1], self._stream()), "dg_axpby")
+
+    def gp_interp(self, real, fake, alpha, xhat):
+        for t in (real, fake, xhat):
+            self._act(t); assert t.is_contiguous() and t.shape == real.shape
+        assert alpha.dtype == torch.float32 and alpha.numel() == real.shape[0]
+        check(self.lib.dg_gp_interp(self.dg, _ptr(real), _ptr(fake), _ptr(alpha), _ptr(xhat), real.shape[0], real[0].numel(), self._stream()), "dg_gp_interp")
+
+    def sumsq_rows(self, g, ss):
+        self._act(g); assert g.is_contiguous() and ss.dtype == torch.float32
+        check(self.lib.dg_sumsq_rows(self.dg, _ptr(g), g.shape[0], g[0].numel(), _ptr(ss), self._stream()), "dg_sumsq_rows")
+
+    def gp_finish(self, ss, B, B_global, gp_lambda, weight, coef, scalar_out):
+        check(self.lib.dg_gp_finish(_ptr(ss), B, B_global, float(gp_lambda), float(weight), _ptr(coef), _ptr(scalar_out), self._stream()), "dg_gp_finish")
+
+    def scale_rows(self, g, coef, out):
+        self._act(g); self._act(out); assert g.is_contiguous() and out.is_contiguous()
+        check(self.lib.dg_scale_rows(self.dg, _ptr(g), _ptr(coef), _ptr(out), g.shape[0], g[0].numel(), self._stream()), "dg_scale_rows")
+
+    def l1(self, a, b, acc, grad=None, grad_scale=0.0, addend=None):
+        self._act(a); self._act(b)
+        assert a.shape == b.shape and acc.dtype == torch.float32
+        lda, rows = pix_layout(a)
+        check(self.lib.dg_l1(self.dg, _ptr(a), lda, _ptr(b), pix_layout(b)[0], rows, a.shape[-1], _ptr(acc), _ptr(grad),
+                             pix_layout(grad)[0] if grad is not None else 0, float(grad_scale), _ptr(addend),
+                             pix_layout(addend)[0] if addend is not None else 0, self._stream()), "dg_l1")
+
+    def sum_strided(self, inp, n, stride, scale, out):
+        assert inp.dtype == torch.float32 and out.dtype == torch.float32
+        check(self.lib.dg_sum_strided(_ptr(inp), n, stride, float(scale), _ptr(out), self._stream()), "dg_sum_strided")
+
+    def fill_col(self, buf, col, value):
+        assert buf.dtype == torch.float32 and buf.dim() == 2
+        check(self.lib.dg_fill_col(_ptr(buf), buf.shape[0], buf.stride(0), col, float(value), self._stream()), "dg_fill_col")
+
+    def adam(self, p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0):
+        for t in (p, g, m, v):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+        if shadow is not None:
+            assert shadow.dtype == torch.bfloat16 and shadow.numel() == p.numel()
+        check(self.lib.dg_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), p.numel(), lr, beta1, beta2, eps, step,
+                               float(grad_scale), self._stream()), "dg_adam")
+
+    def nchw_to_nhwc(self, src, dst):
+        n, c, h, w = src.shape
+        assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape[:3]) == (n, h, w)
+        self._act(dst)
+        check(self.lib.dg_nchw_to_nhwc(self.dg, _ptr(src), _ptr(dst), n, c, h, w, dst.shape[3], self._stream()), "dg_nchw_to_nhwc")
+
+    def nhwc_to_nchw(self, src, dst):
+        n, c, h, w = dst.shape
+        self._act(src)
+        assert dst.dtype == torch.float32 and dst.is_contiguous()
+        check(self.lib.dg_nhwc_to_nchw(self.dg, _ptr(src), pix_layout(src)[0], _ptr(dst), n, c, h, w, self._stream()), "dg_nhwc_to_nchw")
+
+    def cast(self, src, dst):
+        assert src.dtype == torch.float32 and dst.dtype == self.tdtype and src.numel() == dst.numel()
+        check(self.lib.dg_cast(self.dg, _ptr(src), _ptr(dst), src.numel(), self._stream()), "dg_cast")
+
+    # ------------------------------------------------------------------ plumbing (device memory only)
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or self.tdtype, device=self.device)

@@ -1,0 +1,197 @@
+/*
+ * downgan_hip.h — C ABI of libdowngan_hip.so: the MI355X (gfx950) kernels of the DoWnGAN WGAN-GP
+ * train step.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * The reference (nannau/DoWnGAN) has no FFI of its own: its hot path is PyTorch ops called from
+ * DoWnGAN/GAN/wasserstein.py and DoWnGAN/networks/{generator,critic}.py.  Each entry point below
+ * names the reference op / call site it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - Activations are NHWC ("channels-last"), element type `dtype` (DG_F32 or DG_BF16), channel
+ *    counts padded to a multiple of 16, `ld*` = distance between consecutive pixels in ELEMENTS
+ *    (so a tensor may be a channel slice of a wider dense-block slab).  All base pointers and
+ *    channel offsets are 16-byte aligned.
+ *  - Conv weights are packed [Nout][9 taps][Cred] in `dtype` (see dg_repack_conv_weights): the
+ *    forward pack has Nout=Cout, Cred=Cin (KRSC); the dgrad pack has Nout=Cin, Cred=Cout.
+ *  - Master parameters, gradients, Adam moments, biases and all loss scalars are fp32.
+ *  - Ownership: the caller owns every buffer (incl. workspaces); nothing here allocates or frees
+ *    device memory.  Launches are asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - Errors: 0 = DG_OK, negative = dg_status; no exceptions cross the ABI.
+ *  - Re-entrant; no global mutable state.
+ */
+#ifndef DOWNGAN_HIP_H
+#define DOWNGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_F32 0
+#define DG_BF16 1
+
+typedef enum dg_status {
+  DG_OK = 0,
+  DG_ERR_BAD_SHAPE = -1,
+  DG_ERR_BAD_DTYPE = -2,
+  DG_ERR_BAD_ARG = -3,
+  DG_ERR_LAUNCH = -4
+} dg_status;
+
+/* Epilogue applied to every output element v (fp32 accumulator) before the store, in this order:
+ *   v += bias[c]; if (has_act) v = v>0 ? v : v*act_slope;
+ *   if (r1) v = v*s1 + r1[pixel,c];  if (r2) v = v*s2 + r2[pixel,c];
+ *   if (mask) v *= (mask[pixel,c] > 0 ? 1 : mask_slope);     -- LeakyReLU'(saved activation)
+ *   if (accumulate) v += y[pixel,c];
+ * r1/r2/mask are tensors of the OUTPUT's shape in `dtype`. */
+typedef struct dg_epilogue {
+  const float* bias;
+  int has_act;
+  float act_slope;
+  const void* r1; int64_t ldr1; float s1;
+  const void* r2; int64_t ldr2; float s2;
+  const void* mask; int64_t ldmask; float mask_slope;
+  int accumulate;
+} dg_epilogue;
+
+/* Geometry of ONE reference nn.Conv2d(Cin, Cout, kernel_size=3, stride, padding=1) layer
+ * (generator.py:24,62,66,70,77,80; critic.py:21-87), in its FORWARD orientation. */
+typedef struct dg_conv_geom {
+  int dtype;
+  int N, H, W;          /* forward input: N images of H x W                                     */
+  int Cin, Cout;        /* padded channel counts (multiples of 16; Cin may be a multiple of 8)   */
+  int stride;           /* 1 or 2; output is Ho = H/stride, Wo = W/stride (H, W even if 2)       */
+  int pixel_shuffle;    /* 1: the layer is followed by LeakyReLU + nn.PixelShuffle(2)            */
+                        /*    (generator.py:69-75). Output channels are packed (2i+j)*Cout/4 + c */
+                        /*    and the activation tensor is stored shuffled: [N,2Ho,2Wo,Cout/4].  */
+  int64_t ldx;          /* pixel stride of the layer INPUT tensor x  (or of dx in dgrad)         */
+  int64_t ldy;          /* pixel stride of the layer OUTPUT tensor y (or of dy in dgrad/wgrad)   */
+} dg_conv_geom;
+
+/* The generic launch descriptor every conv forward / data-gradient is lowered to: a gather-GEMM
+ *   Y[dst(m), n] = epilogue( sum_{t<ntaps} sum_{c<Cred} X[src(m,t), c] * Wp[n][tap_w[t]][c] )
+ * over GEMM rows m = (img, gy, gx) of an Hg x Wg grid, src(m,t) = (img, gy*sy_mul+tap_dy[t],
+ * gx*sx_mul+tap_dx[t]) (zero outside the source), dst(m) = (img, gy*dy_mul+dy_off, gx*dx_mul+dx_off).
+ * Exposed so that the planner can be checked on a CPU (dg_conv3x3_plan needs no GPU). */
+typedef struct dg_gg_desc {
+  int dtype;
+  int N, Hs, Ws, Cred; int64_t lds;   /* source tensor                                          */
+  int src_ps;                          /* source is stored pixel-shuffled (Cred = 4*Cps)         */
+  int Hg, Wg, sy_mul, sx_mul;
+  int ntaps; int tap_dy[9], tap_dx[9], tap_w[9];
+  int Nout; int64_t ldw;               /* packed weights: row stride in elements (9*Cred)        */
+  int Hd, Wd; int64_t ldd;             /* destination tensor                                     */
+  int dy_mul, dx_mul, dy_off, dx_off;
+  int dst_ps;                          /* store pixel-shuffled (Nout = 4*Cps)                    */
+} dg_gg_desc;
+
+const char* dg_version(void);
+
+/* ---- convolution family (replaces torch.nn.Conv2d forward/backward on the hot path) ---------- */
+
+/* y = epilogue(conv3x3(x, w_fwd)).  Replaces nn.Conv2d.forward (+ fused LeakyReLU / residual /
+ * PixelShuffle): generator.py:36-41,53,62-90; critic.py:101-102. */
+int dg_conv3x3_fwd(const dg_conv_geom* g, const dg_epilogue* ep, const void* x, const void* w_fwd,
+                   void* y, void* stream);
+
+/* dx = epilogue(conv3x3_input_grad(dy, w_dgrad)).  Replaces the autograd input-gradient of
+ * nn.Conv2d (wasserstein.py:52,80 backward; :100-106 autograd.grad for the penalty).  Stride 2 is
+ * done as 4 output-parity classes (no zero insertion).  Epilogue tensors have dx's shape. */
+int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, const void* dy,
+                     const void* w_dgrad, void* dx, void* stream);
+
+/* dw[Cout][9][Cin] (fp32) += sum_pixels dy (x) x   (atomic accumulate).  Replaces the autograd
+ * weight-gradient of nn.Conv2d (wasserstein.py:52,80) and, with (x:=tangent, dy:=adjoint), the
+ * double-backward term of the gradient penalty (wasserstein.py:100-117 under :52). */
+int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void* dy, float* dw, void* stream);
+
+/* db[c] (fp32) += sum over rows of dy[row, c]  (bias gradient of a conv or Linear).  Row r is at
+ * element offset (r / rows_inner)*ld_outer + (r % rows_inner)*ld, so one sub-position of a
+ * pixel-shuffled tensor can be reduced (rows_outer x rows_inner rows in total). */
+int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, int64_t rows_inner,
+              int64_t ld, int C, float* db, void* stream);
+
+/* Launches one gather-GEMM descriptor (what dg_conv3x3_fwd / _dgrad call after planning). */
+int dg_gather_gemm(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w, void* y,
+                   void* stream);
+
+/* Host-only planner (no GPU needed): lowers a layer to its gather-GEMM descriptor(s).
+ * kind 0 = forward (1 desc), kind 1 = dgrad (1 desc for stride 1, 4 parity classes for stride 2).
+ * Returns the number of descriptors written to out[0..3], or a negative dg_status. */
+int dg_conv3x3_plan(const dg_conv_geom* g, int kind, dg_gg_desc* out);
+
+/* Derives the compute-precision weight packs from the fp32 MASTER, which is kept forward-packed and
+ * padded as [CoutP][9][CinP] (tap = r*3+s; for a pixel-shuffle layer the host has already moved
+ * output channel co=4c+2i+j to row (2i+j)*Cout/4 + c, torch PixelShuffle order, generator.py:73):
+ *   kind 0 (forward pack): same layout cast to `dtype`;  kind 1 (dgrad pack): dst[ci][tap][co]. */
+int dg_repack_conv_weights(int dtype, int kind, const float* master, void* dst, int CoutP, int CinP,
+                           void* stream);
+
+/* ---- Linear family (replaces nn.Linear in critic.py:94-105) ---------------------------------- */
+
+/* y[b][o] (fp32, pre-zeroed, ldy) += sum_k x[b][k] * w[o][k]; split-K with atomics. */
+int dg_linear_fwd(int dtype, const void* x, int64_t ldx, const void* w, int64_t ldw, float* y,
+                  int ldy, int B, int O, int64_t K, void* stream);
+/* dx[b][k] = (sum_o dy[b][o] * w[o][k]) * LeakyReLU'(mask[b][k]);  dy fp32 [B][ldo]; dx in
+ * out_dtype (DG_F32 or `dtype`); mask (optional) in `dtype`, same shape as dx. */
+int dg_linear_dx(int dtype, int out_dtype, const float* dy, int ldo, const void* w, int64_t ldw,
+                 void* dx, int64_t lddx, const void* mask, int64_t ldmask, float mask_slope, int B,
+                 int O, int64_t K, void* stream);
+/* dw[o][k] (fp32) += sum_b dy[b][o] * x[b][k]. */
+int dg_linear_dw(int dtype, const float* dy, int ldo, const void* x, int64_t ldx, float* dw,
+                 int64_t lddw, int B, int O, int64_t K, void* stream);
+
+/* ---- elementwise / reductions ----------------------------------------------------------------- */
+
+/* out[r][c] = act(in_f32[r][c] + bias[c]) cast to out_dtype; optional mask multiply instead of act
+ * (tangent pass).  Rows x C small matrices (critic head, critic.py:96-98). */
+int dg_bias_act(int out_dtype, const float* in, int ldi, const float* bias, void* out, int ldo,
+                int rows, int C, int has_act, float slope, const void* mask, int ldmask,
+                float mask_slope, void* stream);
+/* u[p][c] *= LeakyReLU'(y[p][c]) in place over a [rows x C] channel slice. */
+int dg_mask_mul(int dtype, void* u, int64_t ldu, const void* y, int64_t ldy, int64_t rows, int C,
+                float slope, void* stream);
+/* out = a*x + b*y over [rows x C] slices (residual adds, generator.py:41,53,87). y may be NULL. */
+int dg_axpby(int dtype, void* out, int64_t ldo, const void* x, int64_t ldx, float a, const void* y,
+             int64_t ldy, float b, int64_t rows, int C, void* stream);
+/* xhat[b] = alpha[b]*real[b] + (1-alpha[b])*fake[b]   (wasserstein.py:94). per_img = elements/image */
+int dg_gp_interp(int dtype, const void* real, const void* fake, const float* alpha, void* xhat,
+                 int B, int64_t per_img, void* stream);
+/* ss[b] (fp32, pre-zeroed) += sum of squares of image b   (wasserstein.py:114), wave-shuffle reduce */
+int dg_sumsq_rows(int dtype, const void* g, int B, int64_t per_img, float* ss, void* stream);
+/* From ss[b]: n_b = sqrt(ss+1e-12); scalars[0] = gp_lambda*mean((n_b-1)^2)  (wasserstein.py:117);
+ * coef[b] = weight * gp_lambda * (2/B_global) * (n_b-1)/n_b  (d/dg of weight*gp_ret). */
+int dg_gp_finish(const float* ss, int B, int B_global, float gp_lambda, float weight, float* coef,
+                 float* scalars, void* stream);
+/* out[b] = coef[b] * g[b]  (per-image scale) */
+int dg_scale_rows(int dtype, const void* g, const float* coef, void* out, int B, int64_t per_img,
+                  void* stream);
+/* L1 content loss (losses.py:51-53): acc[0] (fp32, pre-zeroed) += sum |a-b| over [rows x C] with C
+ * real channels of ld-strided pixels; if grad: grad = grad_scale*sign(a-b) (+ addend if given). */
+int dg_l1(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int C,
+          float* acc, void* grad, int64_t ldg, float grad_scale, const void* addend, int64_t ldadd,
+          void* stream);
+/* out[0] = scale * sum_{i<n} in[i*stride]  (means of critic outputs, wasserstein.py:46-47,74) */
+int dg_sum_strided(const float* in, int n, int stride, float scale, float* out, void* stream);
+/* fill fp32 buffer with a constant on a strided column (grad_outputs=ones, wasserstein.py:103) */
+int dg_fill_col(float* buf, int rows, int ld, int col, float value, void* stream);
+
+/* Adam (stage.py:63-64: lr 2.5e-4, betas (0.9,0.99), eps 1e-8, no weight decay) over a flat fp32
+ * buffer; also refreshes the bf16 shadow copy when shadow != NULL.  grad_scale multiplies g first
+ * (1/world_size after a sum all-reduce). */
+int dg_adam(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+            float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* Layout converters between the reference's NCHW fp32 tensors and native NHWC padded `dtype`. */
+int dg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cpad,
+                    void* stream);
+int dg_nhwc_to_nchw(int dtype, const void* src, int64_t lds, float* dst, int N, int C, int H, int W,
+                    void* stream);
+/* fp32 -> dtype cast of n elements (weight shadows) */
+int dg_cast(int dtype, const float* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOWNGAN_HIP_H */

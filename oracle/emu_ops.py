@@ -1,0 +1,234 @@
+"""TEST INFRASTRUCTURE — torch-CPU emulation of the op contracts of ``downgan_amd.ops.HipOps``.
+
+Purpose: run the host-side engine (buffer plumbing, slab offsets, hand-derived backward and
+double-backward chains) on a machine without a GPU and compare it with ``oracle/ref_step.py``.
+The conv ops go through the REAL host planner of libdowngan_hip.so (``dg_conv3x3_plan``, which needs
+no GPU) and then evaluate the planned gather-GEMM descriptor with plain torch indexing, so the
+planner's tap/parity-class logic is covered by the CPU test-suite too.
+
+Never imported by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from downgan_amd import _lib
+from downgan_amd.ops import Conv, pix_layout
+
+TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16}
+DG_DTYPE = {"f32": _lib.DG_F32, "bf16": _lib.DG_BF16}
+
+
+def _lgrad(y, slope):
+    return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+
+
+class EmuOps:
+    name = "emu"
+
+    def __init__(self, dtype="f32", device="cpu"):
+        self.dtype = dtype
+        self.tdtype = TORCH_DTYPE[dtype]
+        self.dg = DG_DTYPE[dtype]
+        self.device = torch.device(device)
+        self.lib = _lib.lib()
+
+    # ------------------------------------------------------------------ conv family
+    def out_shape(self, cv: Conv):
+        if cv.pixel_shuffle:
+            return (cv.N, 2 * cv.Ho, 2 * cv.Wo, cv.Cout // 4)
+        return (cv.N, cv.Ho, cv.Wo, cv.Cout)
+
+    def _plan(self, cv: Conv, kind, ldx, ldy):
+        g = _lib.ConvGeom(dtype=self.dg, N=cv.N, H=cv.H, W=cv.W, Cin=cv.Cin, Cout=cv.Cout, stride=cv.stride,
+                          pixel_shuffle=int(cv.pixel_shuffle), ldx=ldx, ldy=ldy)
+        d = (_lib.GGDesc * 4)()
+        n = self.lib.dg_conv3x3_plan(C.byref(g), kind, d)
+        assert n > 0, n
+        return [d[i] for i in range(n)]
+
+    def _gather_gemm(self, d, x, w, y, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None,
+                     mask_slope=1.0, accumulate=False):
+        N = d.N
+        xs = x.float()
+        if d.src_ps:
+            cps = d.Cred // 4
+            assert tuple(xs.shape) == (N, 2 * d.Hs, 2 * d.Ws, cps)
+            xs = xs.view(N, d.Hs, 2, d.Ws, 2, cps).permute(0, 1, 3, 2, 4, 5).reshape(N, d.Hs, d.Ws, 4 * cps)
+        assert tuple(xs.shape) == (N, d.Hs, d.Ws, d.Cred), (xs.shape, d.Hs, d.Ws, d.Cred)
+        Wp = w.float().view(d.Nout, 9, d.Cred)
+        assert d.ldw == 9 * d.Cred
+        gy = torch.arange(d.Hg)
+        gx = torch.arange(d.Wg)
+        acc = torch.zeros(N, d.Hg, d.Wg, d.Nout)
+        for t in range(d.ntaps):
+            sy = gy * d.sy_mul + d.tap_dy[t]
+            sx = gx * d.sx_mul + d.tap_dx[t]
+            vy = (sy >= 0) & (sy < d.Hs)
+            vx = (sx >= 0) & (sx < d.Ws)
+            patch = xs[:, sy.clamp(0, d.Hs - 1)][:, :, sx.clamp(0, d.Ws - 1)]
+            patch = patch * (vy[:, None] & vx[None, :])[None, :, :, None]
+            acc += torch.einsum("nhwc,oc->nhwo", patch, Wp[:, d.tap_w[t], :])
+        if d.dst_ps:
+            cps = d.Nout // 4
+            acc = acc.view(N, d.Hg, d.Wg, 2, 2, cps).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * d.Hg, 2 * d.Wg, cps)
+            sl = (slice(None), slice(None), slice(None))
+            bias_v = None
+            if bias is not None:  # bias is in packed (q*cps + c) order -> broadcast per sub-position
+                bias_v = bias[:d.Nout].view(2, 2, cps)[None, None, :, None, :, :].expand(N, d.Hg, 2, d.Wg, 2, cps).reshape(N, 2 * d.Hg, 2 * d.Wg, cps)
+        else:
+            sl = (slice(None), slice(d.dy_off, None, d.dy_mul), slice(d.dx_off, None, d.dx_mul))
+            bias_v = bias[:d.Nout] if bias is not None else None
+        ysub = y[sl]
+        assert tuple(ysub.shape) == tuple(acc.shape), (ysub.shape, acc.shape)
+        v = acc
+        if bias_v is not None:
+            v = v + bias_v
+        if act is not None:
+            v = torch.where(v > 0, v, v * act)
+        if r1 is not None:
+            v = v * s1 + r1[sl].float()
+        if r2 is not None:
+            v = v * s2 + r2[sl].float()
+        if mask is not None:
+            v = v * _lgrad(mask[sl].float(), mask_slope)
+        if accumulate:
+            v = v + ysub.float()
+        ysub.copy_(v.to(y.dtype))
+
+    def conv_fwd(self, cv: Conv, x, w_fwd, y, **ep):
+        assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(y.shape) == self.out_shape(cv)
+        (d,) = self._plan(cv, 0, pix_layout(x)[0], pix_layout(y)[0])
+        self._gather_gemm(d, x, w_fwd, y, **ep)
+
+    def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, **ep):
+        assert tuple(dx.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(dy.shape) == self.out_shape(cv)
+        for d in self._plan(cv, 1, pix_layout(dx)[0], pix_layout(dy)[0]):
+            self._gather_gemm(d, dy, w_dgrad, dx, **ep)
+
+    def conv_wgrad(self, cv: Conv, x, dy, dw):
+        u = dy.float()
+        if cv.pixel_shuffle:
+            cps = cv.Cout // 4
+            u = u.view(cv.N, cv.Ho, 2, cv.Wo, 2, cps).permute(0, 1, 3, 2, 4, 5).reshape(cv.N, cv.Ho, cv.Wo, cv.Cout)
+        xp = torch.nn.functional.pad(x.float(), (0, 0, 1, 1, 1, 1))
+        g = dw.view(cv.Cout, 9, cv.Cin)
+        st = cv.stride
+        for r in range(3):
+            for s in range(3):
+                patch = xp[:, r:r + st * cv.Ho:st, s:s + st * cv.Wo:st, :]
+                g[:, r * 3 + s, :] += torch.einsum("nhwo,nhwc->oc", u, patch)
+
+    def colsum(self, dy, db):
+        Cc = dy.shape[-1]
+        db[:Cc] += dy.float().reshape(-1, Cc).sum(0)
+
+    def colsum_ps(self, dy, db):
+        f = dy.shape[-1]
+        for i in range(2):
+            for j in range(2):
+                db[(2 * i + j) * f:(2 * i + j + 1) * f] += dy[:, i::2, j::2, :].float().reshape(-1, f).sum(0)
+
+    def repack(self, master, dst, cout, cin, kind):
+        m = master.view(cout, 9, cin)
+        if kind == 0:
+            dst.copy_(m.reshape(-1).to(dst.dtype))
+        else:
+            dst.copy_(m.permute(2, 1, 0).reshape(-1).to(dst.dtype))
+
+    # ------------------------------------------------------------------ linear family
+    def linear_fwd(self, x, w, y):
+        O = w.shape[0]
+        y[:, :O] += x.float() @ w.float().t()
+
+    def linear_dx(self, dy, w, dx, mask=None, mask_slope=1.0):
+        O = w.shape[0]
+        v = dy[:, :O] @ w.float()
+        if mask is not None:
+            v = v * _lgrad(mask.float(), mask_slope)
+        dx.copy_(v.to(dx.dtype))
+
+    def linear_dw(self, dy, x, dw):
+        O = dw.shape[0]
+        dw += dy[:, :O].t() @ x.float()
+
+    def bias_act(self, inp, bias, out, act=None, mask=None, mask_slope=1.0):
+        Cc = out.shape[1]
+        v = inp[:, :Cc].clone()
+        if bias is not None:
+            v = v + bias[:Cc]
+        if act is not None:
+            v = torch.where(v > 0, v, v * act)
+        if mask is not None:
+            v = v * _lgrad(mask.float(), mask_slope)
+        out.copy_(v.to(out.dtype))
+
+    # ------------------------------------------------------------------ elementwise
+    def mask_mul(self, u, y, slope):
+        u.copy_((u.float() * _lgrad(y.float(), slope)).to(u.dtype))
+
+    def axpby(self, out, x, a=1.0, y=None, b=0.0):
+        v = a * x.float()
+        if y is not None:
+            v = v + b * y.float()
+        out.copy_(v.to(out.dtype))
+
+    def gp_interp(self, real, fake, alpha, xhat):
+        a = alpha.view(-1, 1, 1, 1)
+        xhat.copy_((a * real.float() + (1 - a) * fake.float()).to(xhat.dtype))
+
+    def sumsq_rows(self, g, ss):
+        ss += (g.float() ** 2).reshape(g.shape[0], -1).sum(1)
+
+    def gp_finish(self, ss, B, B_global, gp_lambda, weight, coef, scalar_out):
+        n = torch.sqrt(ss[:B] + 1e-12)
+        d = n - 1
+        coef[:B] = weight * gp_lambda * (2.0 / B_global) * d / n
+        scalar_out[0] = gp_lambda * (d * d).sum() / B_global
+
+    def scale_rows(self, g, coef, out):
+        out.copy_((g.float() * coef[:g.shape[0]].view(-1, 1, 1, 1)).to(out.dtype))
+
+    def l1(self, a, b, acc, grad=None, grad_scale=0.0, addend=None):
+        d = a.float() - b.float()
+        acc[0] += d.abs().sum()
+        if grad is not None:
+            g = torch.sign(d) * grad_scale
+            if addend is not None:
+                g = g + addend.float()
+            grad.copy_(g.to(grad.dtype))
+
+    def sum_strided(self, inp, n, stride, scale, out):
+        out[0] = inp.reshape(-1)[:n * stride:stride].sum() * scale
+
+    def fill_col(self, buf, col, value):
+        buf[:, col] = value
+
+    def adam(self, p, g, m, v, shadow, lr, beta1, beta2, eps, step, grad_scale=1.0):
+        gg = g * grad_scale
+        m.mul_(beta1).add_(gg, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        bc1 = 1 - beta1 ** step
+        bc2 = 1 - beta2 ** step
+        denom = v.sqrt() / (bc2 ** 0.5) + eps
+        p.addcdiv_(m, denom, value=-lr / bc1)
+        if shadow is not None:
+            shadow.copy_(p.to(shadow.dtype))
+
+    def nchw_to_nhwc(self, src, dst):
+        dst.zero_()
+        dst[..., :src.shape[1]] = src.permute(0, 2, 3, 1).to(dst.dtype)
+
+    def nhwc_to_nchw(self, src, dst):
+        dst.copy_(src[..., :dst.shape[1]].float().permute(0, 3, 1, 2))
+
+    def cast(self, src, dst):
+        dst.copy_(src.view(dst.shape).to(dst.dtype))
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.tdtype)
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or self.tdtype)
