@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — train-step samples/sec (G+D+GP) of the native WGAN-GP step on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 is launched by torch.distributed.run,
+one rank per GPU over RCCL).  A "step" is one minibatch through the critic iteration plus the
+generator iteration when step % 5 == 0 (reference DoWnGAN/GAN/wasserstein.py:131-147; the metrics
+pass :140 is excluded).  Workload at N=1 = BASELINE.json configs[1]: batch 32 per GPU, 2-channel
+128x128 -> 1024x1024 tiles, filters 128, 16 RRDBs, bf16 storage + bf16 MFMA with fp32 accumulate,
+fp32 master weights / Adam.  Inputs are synthetic N(0,1) tiles resident in HBM in native NHWC layout
+before the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (batch per GPU, coarse side, filters, channels, RRDBs)
+    "cfg2": (32, 128, 128, 2, 16),          # BASELINE.json configs[1] (and [2] at 8 GPUs: global batch 256)
+    "cfg4": (16, 128, 128, 6, 16),          # 6-covariate input, global batch 64 on 4 GPUs
+    "cfg1": (4, 16, 16, 2, 16),             # the reference's CPU-runnable plumbing case
+    "mid": (4, 64, 64, 2, 4),               # small GPU sanity workload
+}
+
+
+def conv_flops_per_sample(S, F_, cin_p, np_p, nrb, nup=3):
+    """Forward GFLOP/sample of generator (Gf) and critic (Cf) convs+linears, padded channels."""
+    gf = 2 * 9 * cin_p * F_ * S * S
+    gf += nrb * 3 * sum(2 * 9 * k * F_ * F_ * S * S for k in range(1, 6))
+    gf += 2 * 9 * F_ * F_ * S * S
+    for u in range(nup):
+        gf += 2 * 9 * F_ * 4 * F_ * (S << u) ** 2
+    hs = S << nup
+    gf += 2 * 9 * F_ * F_ * hs * hs + 2 * 9 * F_ * np_p * hs * hs
+    widths = [np_p, F_, F_, 2 * F_, 2 * F_, 4 * F_, 4 * F_, 8 * F_, 8 * F_]
+    strides = (1, 2, 1, 2, 1, 2, 1, 2)
+    cf, h = 0, hs
+    for l, st in enumerate(strides):
+        h //= st
+        cf += 2 * 9 * widths[l] * widths[l + 1] * h * h
+    cf += 2 * (8 * F_ * h * h) * 100 + 2 * 100
+    return gf, cf
+
+
+def cpu_baseline(args, wl):
+    """The CPU oracle (a port: oracle/ref_step.py, PyTorch-CPU fp32) timed on this box's host cores on a
+    bounded sample of the same workload: ONE critic iteration (+ one generator iteration if time
+    allows) at the workload's tile shapes with batch 1."""
+    import torch
+    from downgan_amd import synthetic
+    from oracle import ref_step
+    B, S, F_, cin, nrb = wl
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    pg = {k: torch.from_numpy(v) for k, v in synthetic.generator_params(F_, cin, 2, nrb).items()}
+    pc = {k: torch.from_numpy(v) for k, v in synthetic.critic_params(F_, 8 * S, 2).items()}
+    tr = ref_step.OracleTrainer(pg, pc, ref_step.HP(batch_size=1), num_res_blocks=nrb)
+    coarse, fine = synthetic.tiles(1, cin, S)
+    coarse, fine = torch.from_numpy(coarse), torch.from_numpy(fine)
+    alpha = torch.from_numpy(synthetic.alpha(1, 0))
+    t0 = time.perf_counter()
+    tr.critic_iteration(coarse, fine, alpha)
+    tc = time.perf_counter() - t0
+    gf, cf = conv_flops_per_sample(S, F_, cin, 2, nrb)
+    if tc < 25.0:
+        t0 = time.perf_counter()
+        tr.generator_iteration(coarse, fine)
+        tg = time.perf_counter() - t0
+        sample = f"1 critic + 1 generator iteration, batch 1, {cin}ch {S}x{S}->{8 * S}x{8 * S}, F={F_}, fp32, measured {tc:.1f}s + {tg:.1f}s"
+    else:
+        tg = tc * (3 * gf + 2 * cf) / (gf + 10 * cf)
+        sample = (f"1 critic iteration, batch 1, {cin}ch {S}x{S}->{8 * S}x{8 * S}, F={F_}, fp32, measured {tc:.1f}s; "
+                  f"generator iteration extrapolated by flop ratio to {tg:.1f}s")
+    return {"value": 1.0 / (tc + tg / 5.0), "unit": "samples/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from downgan_amd import synthetic
+    from downgan_amd.dist import Dist
+    from downgan_amd.engine import HyperParams, TrainEngine
+    from downgan_amd.ops import HipOps
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dist = Dist("nccl") if world > 1 else None
+    rank = dist.rank if dist else 0
+    local = dist.local_rank if dist else 0
+    torch.cuda.set_device(local)
+    B, S, F_, cin, nrb = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    ops = HipOps(args.dtype, f"cuda:{local}")
+    eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B * world), num_res_blocks=nrb, dist=dist)
+    eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))       # seed 0 on every rank
+    eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
+    coarse, fine = synthetic.tiles(B, cin, S, rank=rank)                      # seed 1234 + rank
+    xc = ops.zeros(B, S, S, eng.G.cin_p); ops.nchw_to_nhwc(torch.from_numpy(coarse).cuda(), xc)
+    xf = ops.zeros(B, 8 * S, 8 * S, eng.G.np_p); ops.nchw_to_nhwc(torch.from_numpy(fine).cuda(), xf)
+    del coarse, fine
+    nsteps = args.warmup + args.steps
+    alphas = [torch.from_numpy(synthetic.alpha(B, s, rank=rank)).cuda() for s in range(nsteps)]
+
+    for s in range(args.warmup):
+        eng.train_step(xc, xf, alphas[s])
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_timing:
+        ops.prof = []
+    t0 = time.perf_counter()
+    for s in range(args.warmup, nsteps):
+        eng.train_step(xc, xf, alphas[s])
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64).cuda()
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    scal = eng.read_scalars(True)
+
+    roofline = None
+    kernels = {}
+    if ops.prof:
+        agg = {}
+        for tag, flops, s_ev, e_ev in ops.prof:
+            a = agg.setdefault(tag, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += s_ev.elapsed_time(e_ev) * 1e-3; a[2] += 1
+        for tag, (fl, sec, n) in agg.items():
+            kernels[tag] = {"launches": n, "seconds": round(sec, 4), "tflops": round(fl / sec / 1e12, 2) if sec > 0 else None}
+        # dominant kernel: the gather-GEMM conv kernel (forward + data-gradient launches of gg_kernel)
+        fl = sum(agg[t][0] for t in ("conv_fwd", "conv_dgrad") if t in agg)
+        sec = sum(agg[t][1] for t in ("conv_fwd", "conv_dgrad") if t in agg)
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        ach = fl / sec / 1e12
+        roofline = {"kernel": "gg_kernel (implicit-GEMM conv3x3 forward + data-gradient)", "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None}
+        ops.prof = None
+
+    if rank == 0:
+        gf, cf = conv_flops_per_sample(S, F_, eng.G.cin_p, eng.G.np_p, nrb)
+        value = args.steps * B * world / elapsed
+        w_step = (1.6 * gf + 10.4 * cf)
+        out = {
+            "metric": "train-step samples/sec (G+D+GP)", "value": round(value, 4), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: batch {B}/GPU (global {B * world}), {cin}ch {S}x{S}->{8 * S}x{8 * S}, "
+                                   f"filters {F_}, {nrb} RRDBs, WGAN-GP critic step every step + generator step every 5th",
+                       "parallelism": f"dp{world}", "alg_tflop_per_sample_step": round(w_step / 1e12, 4)},
+            "step_mfma_frac": round(w_step * value / world / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4),
+            "losses": {k: scal[k] for k in ("critic_loss", "gp_ret", "g_loss") if k in scal},
+            "roofline": roofline, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, (B, S, F_, cin, nrb))
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""Drop-in mirror of the reference trainer (reference DoWnGAN/GAN/wasserstein.py:16-189).
+
+``WassersteinGAN(G, C, G_optimizer, C_optimizer)`` with the same method names and argument meaning.
+Differences, all additive: the iteration methods RETURN the scalars the reference computes and drops
+(:46-50, :74-78); ``alpha`` can be injected into ``_critic_train_iteration`` / ``_gp`` (the reference
+draws it from the device RNG at :91); Adam is the fused native kernel configured from
+``config.hyperparams`` (the optimizer arguments are accepted for signature compatibility and may be
+None).  mlflow logging / plotting of the reference's epoch loop (:140-179) is out of scope.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..config import hyperparams as hp
+from ..engine import TrainEngine
+from ..ops import HipOps
+
+
+class WassersteinGAN:
+    def __init__(self, G, C, G_optimizer=None, C_optimizer=None, dist=None) -> None:
+        self.G, self.C = G, C
+        self.G_optimizer, self.C_optimizer = G_optimizer, C_optimizer
+        self.num_steps = 0
+        self.dist = dist
+        self._engine = None
+        self._stage = None
+        self.last = {}
+
+    def _eng(self, coarse, fine):
+        B, cin, S, _ = coarse.shape
+        if self._engine is None or (self._engine.B, self._engine.S) != (B, S):
+            assert self.G.dtype == self.C.dtype
+            ops = HipOps(self.G.dtype, self.G.device)
+            e = TrainEngine(ops, S, self.G.filters, cin, B, hp.as_engine_hp(B), self.G.n_predictands,
+                            self.G.num_res_blocks, self.G.num_upsample, dist=self.dist)
+            self.G.bind(e.G)
+            self.C.bind(e.C)
+            e.num_steps = self.num_steps
+            self._engine = e
+            self._stage = (ops.zeros(B, S, S, e.G.cin_p), ops.zeros(B, fine.shape[2], fine.shape[3], e.G.np_p))
+        return self._engine
+
+    def _to_native(self, e, coarse, fine):
+        o = e.ops
+        xc, xf = self._stage
+        o.nchw_to_nhwc(coarse.to(device=o.device, dtype=torch.float32).contiguous(), xc)
+        o.nchw_to_nhwc(fine.to(device=o.device, dtype=torch.float32).contiguous(), xf)
+        return xc, xf
+
+    def _alpha(self, e, alpha):
+        if alpha is None:
+            return torch.rand(e.B, device=e.ops.device, dtype=torch.float32)     # wasserstein.py:91
+        return torch.as_tensor(alpha, dtype=torch.float32).reshape(-1).to(e.ops.device)
+
+    def _critic_train_iteration(self, coarse, fine, alpha=None):
+        e = self._eng(coarse, fine)
+        xc, xf = self._to_native(e, coarse, fine)
+        e.critic_iteration(xc, xf, self._alpha(e, alpha))
+        self.last = e.read_scalars(False)
+        return self.last
+
+    def _generator_train_iteration(self, coarse, fine):
+        e = self._eng(coarse, fine)
+        xc, xf = self._to_native(e, coarse, fine)
+        e.generator_iteration(xc, xf)
+        out = e.read_scalars(True)
+        self.last.update({k: out[k] for k in ("g_loss", "content_loss", "g_c_fake_mean")})
+        return {k: out[k] for k in ("g_loss", "content_loss", "g_c_fake_mean")}
+
+    def _gp(self, real, fake, critic=None, alpha=None):
+        """Value of gp_lambda * mean((||grad||-1)^2) (wasserstein.py:87-117) for NCHW real / fake."""
+        B = real.shape[0]
+        e = self._engine
+        assert e is not None and e.B == B, "call a train iteration first (buffers are shape-bound)"
+        o = e.ops
+        xr = o.zeros(*e.xhat.shape); o.nchw_to_nhwc(real.to(o.device, torch.float32).contiguous(), xr)
+        xk = o.zeros(*e.xhat.shape); o.nchw_to_nhwc(fake.to(o.device, torch.float32).contiguous(), xk)
+        o.gp_interp(xr, xk, self._alpha(e, alpha), e.xhat)
+        e.C.forward(e.xhat)
+        e.C.backward(e.xhat, 1.0, wgrad=False, dx=e.gbuf)
+        e.ss.zero_()
+        o.sumsq_rows(e.gbuf, e.ss)
+        o.gp_finish(e.ss, B, B * e.world, e.hp.gp_lambda, 0.0, e.coef, e._sc("gp_ret"))
+        return float(e._sc("gp_ret").item())
+
+    def _train_epoch(self, dataloader, testdataloader=None, epoch=0):
+        """wasserstein.py:120-147 without the metrics / plotting / checkpoint side effects."""
+        log = []
+        for data in dataloader:
+            coarse, fine = data[0], data[1]
+            out = dict(self._critic_train_iteration(coarse, fine))
+            if self.num_steps % hp.critic_iterations == 0:                        # :136
+                out.update(self._generator_train_iteration(coarse, fine))
+            self.num_steps += 1
+            if self._engine is not None:
+                self._engine.num_steps = self.num_steps
+            log.append(out)
+        return log
+
+    def train(self, dataloader, testdataloader=None, epochs=None):
+        """wasserstein.py:181-189."""
+        self.num_steps = 0
+        history = []
+        for epoch in range(hp.epochs if epochs is None else epochs):
+            history.append(self._train_epoch(dataloader, testdataloader, epoch))
+        return history

@@ -1,0 +1,59 @@
+"""Data parallelism over the GPUs of one node: one process per GPU, torch.distributed with the
+``nccl`` backend (= RCCL over xGMI on ROCm).  The reference is single-device
+(reference DoWnGAN/config/config.py:25); this is the new component of SURVEY.md §8(e).
+
+Each network keeps ONE flat fp32 gradient buffer, so the exchange is a handful of large in-place
+all-reduces (bucketed so that several can be in flight on RCCL's stream while the next bucket is
+enqueued) instead of one call per parameter.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as td
+
+
+class Dist:
+    def __init__(self, backend=None, bucket_elems=64 * 1024 * 1024):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.bucket_elems = bucket_elems
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        self.backend = backend
+        if self.world_size > 1 and not td.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+            td.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+
+    def allreduce_sum_(self, flat: torch.Tensor):
+        if self.world_size == 1:
+            return
+        works = []
+        n = flat.numel()
+        for off in range(0, n, self.bucket_elems):
+            works.append(td.all_reduce(flat[off:min(n, off + self.bucket_elems)], op=td.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+
+    def reduce_scalars(self, d: dict, mean=(), total=()):
+        if self.world_size == 1:
+            return d
+        keys = list(mean) + list(total)
+        t = torch.tensor([d[k] for k in keys], dtype=torch.float64)
+        if self.backend == "nccl":
+            t = t.cuda()
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        vals = t.cpu().tolist()
+        out = dict(d)
+        for k, v in zip(keys, vals):
+            out[k] = v / self.world_size if k in mean else v
+        return out
+
+    def barrier(self):
+        if self.world_size > 1:
+            td.barrier()

@@ -71,10 +71,27 @@ class HipOps:
         self.dg = DG_DTYPE[dtype]
         self.device = torch.device(device)
         self.lib = _lib.lib()
+        self.prof = None      # optional list of (tag, flops, start_event, end_event): bench.py's live kernel timing
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _timed(self, tag, flops, fn):
+        """Run one launch; when profiling is on, bracket it with HIP events on the launch stream."""
+        if self.prof is None:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn()
+        e.record()
+        self.prof.append((tag, flops, s, e))
+        return rc
+
+    @staticmethod
+    def conv_flops(cv):
+        """algorithmic flops of one conv pass: 2*9*Cin*Cout*Ho*Wo per image, padded channels."""
+        return 2.0 * 9 * cv.Cin * cv.Cout * cv.Ho * cv.Wo * cv.N
 
     def _act(self, t):
         assert t.dtype == self.tdtype and t.is_cuda, (t.dtype, t.device)
@@ -89,7 +106,7 @@ class HipOps:
         ep = Epilogue()
         ep.bias = bias.data_ptr() if bias is not None else None
         if bias is not None:
-            assert bias.dtype == torch.float32 and bias.numel() >= out.shape[-1] * (4 if False else 1)
+            assert bias.dtype == torch.float32 and bias.numel() >= out.shape[-1]
         ep.has_act = int(act is not None)
         ep.act_slope = float(act) if act is not None else 1.0
         for name, t, s in (("r1", r1, s1), ("r2", r2, s2)):
@@ -121,7 +138,8 @@ class HipOps:
         assert w_fwd.numel() == cv.Cout * 9 * cv.Cin and w_fwd.is_contiguous()
         g = self._geom(cv, pix_layout(x)[0], pix_layout(y)[0])
         e = self._epilogue(y, **ep)
-        check(self.lib.dg_conv3x3_fwd(C.byref(g), C.byref(e), _ptr(x), _ptr(w_fwd), _ptr(y), self._stream()), "dg_conv3x3_fwd")
+        check(self._timed("conv_fwd", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_fwd(
+            C.byref(g), C.byref(e), _ptr(x), _ptr(w_fwd), _ptr(y), self._stream())), "dg_conv3x3_fwd")
 
     def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, **ep):
         self._act(dy); self._act(dx); self._act(w_dgrad)
@@ -130,7 +148,8 @@ class HipOps:
         assert w_dgrad.numel() == cv.Cout * 9 * cv.Cin and w_dgrad.is_contiguous()
         g = self._geom(cv, pix_layout(dx)[0], pix_layout(dy)[0])
         e = self._epilogue(dx, **ep)
-        check(self.lib.dg_conv3x3_dgrad(C.byref(g), C.byref(e), _ptr(dy), _ptr(w_dgrad), _ptr(dx), self._stream()), "dg_conv3x3_dgrad")
+        check(self._timed("conv_dgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_dgrad(
+            C.byref(g), C.byref(e), _ptr(dy), _ptr(w_dgrad), _ptr(dx), self._stream())), "dg_conv3x3_dgrad")
 
     def conv_wgrad(self, cv: Conv, x, dy, dw):
         self._act(x); self._act(dy)
@@ -138,7 +157,8 @@ class HipOps:
         assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin), (x.shape, cv)
         assert tuple(dy.shape) == self.out_shape(cv), (dy.shape, cv)
         g = self._geom(cv, pix_layout(x)[0], pix_layout(dy)[0])
-        check(self.lib.dg_conv3x3_wgrad(C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), self._stream()), "dg_conv3x3_wgrad")
+        check(self._timed("conv_wgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad(
+            C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), self._stream())), "dg_conv3x3_wgrad")
 
     def colsum(self, dy, db):
         """db[c] += sum over all pixels/rows of dy[..., c]; dy is NHWC (any dtype of {fp32, compute}) or 2-D."""

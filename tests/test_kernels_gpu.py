@@ -1,0 +1,249 @@
+"""GPU parity of every HIP kernel (through the C ABI) against the CPU oracle ops (oracle/emu_ops.py,
+itself pinned to torch conv/autograd in tests/test_emu_ops_cpu.py).  fp32 kernels must agree to fp32
+re-association noise; bf16 kernels are compared with the oracle evaluated on the same bf16-rounded
+inputs (tolerance = bf16 output rounding + fp32 accumulation order)."""
+import pytest
+import torch
+
+from downgan_amd.ops import Conv, HipOps
+from oracle.emu_ops import EmuOps
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": dict(rtol=2e-5, atol=2e-5), "bf16": dict(rtol=1.6e-2, atol=1.6e-2)}
+
+
+def pair(dtype):
+    return HipOps(dtype), EmuOps(dtype)
+
+
+def rnd(shape, dtype, gen, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).to(dtype)
+
+
+def close(a, b, dtype, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    tol = TOL[dtype]
+    scale = max(1.0, float(b.abs().max()))
+    err = (a - b).abs().max().item()
+    assert err <= tol["atol"] * scale, f"{what}: max err {err:.3e} (scale {scale:.3e}); worst idx {(a - b).abs().argmax().item()}"
+
+
+CONVS = [
+    # N, H, W, Cin, Cout, stride, ps
+    (2, 16, 16, 16, 16, 1, False),
+    (2, 16, 16, 16, 16, 2, False),
+    (1, 12, 20, 32, 64, 1, False),
+    (1, 12, 20, 64, 32, 2, False),
+    (2, 8, 8, 128, 128, 1, False),
+    (1, 16, 16, 128, 256, 2, False),
+    (1, 8, 8, 256, 128, 1, False),
+    (2, 16, 16, 16, 64, 1, True),
+    (1, 8, 8, 64, 256, 1, True),
+    (1, 20, 12, 80, 48, 1, False),
+    (3, 6, 10, 16, 128, 1, False),
+    (1, 32, 32, 128, 16, 1, False),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_fwd(dtype, cfg):
+    N, H, W, ci, co, st, ps = cfg
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(1)
+    cv = Conv(N, H, W, ci, co, st, ps)
+    x = rnd((N, H, W, ci), emu.tdtype, g)
+    w = rnd((co * 9 * ci,), emu.tdtype, g, 0.1)
+    b = torch.randn(co, generator=g)
+    osh = emu.out_shape(cv)
+    r1 = rnd(osh, emu.tdtype, g)
+    r2 = rnd(osh, emu.tdtype, g)
+    for variant in range(4):
+        ep = [dict(bias=b, act=0.2), dict(bias=b, r1=r1, s1=0.2, r2=r2, s2=0.2), dict(mask=r1, mask_slope=0.2), dict(act=0.01, accumulate=True)][variant]
+        y_ref = rnd(osh, emu.tdtype, torch.Generator().manual_seed(5))
+        y = y_ref.clone().cuda()
+        emu.conv_fwd(cv, x, w, y_ref, **ep)
+        epg = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ep.items()}
+        hip.conv_fwd(cv, x.cuda(), w.cuda(), y, **epg)
+        close(y, y_ref, dtype, f"fwd {cfg} variant {variant}")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_dgrad(dtype, cfg):
+    N, H, W, ci, co, st, ps = cfg
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(2)
+    cv = Conv(N, H, W, ci, co, st, ps)
+    dy = rnd(emu.out_shape(cv), emu.tdtype, g)
+    wd = rnd((co * 9 * ci,), emu.tdtype, g, 0.1)
+    mask = rnd((N, H, W, ci), emu.tdtype, g)
+    for ep in (dict(), dict(mask=mask, mask_slope=0.2), dict(accumulate=True)):
+        dx_ref = rnd((N, H, W, ci), emu.tdtype, torch.Generator().manual_seed(6))
+        dx = dx_ref.clone().cuda()
+        emu.conv_dgrad(cv, dy, wd, dx_ref, **ep)
+        hip.conv_dgrad(cv, dy.cuda(), wd.cuda(), dx, **{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ep.items()})
+        close(dx, dx_ref, dtype, f"dgrad {cfg} {list(ep)}")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_wgrad(dtype, cfg):
+    N, H, W, ci, co, st, ps = cfg
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(3)
+    cv = Conv(N, H, W, ci, co, st, ps)
+    x = rnd((N, H, W, ci), emu.tdtype, g)
+    dy = rnd(emu.out_shape(cv), emu.tdtype, g)
+    dw_ref = torch.randn(co * 9 * ci, generator=g)
+    dw = dw_ref.clone().cuda()
+    emu.conv_wgrad(cv, x, dy, dw_ref)
+    hip.conv_wgrad(cv, x.cuda(), dy.cuda(), dw)
+    a, b = dw.cpu(), dw_ref
+    scale = float(b.abs().max())
+    tol = 1e-5 if dtype == "f32" else 1e-4   # inputs are identical bf16 values; accumulation is fp32 in both
+    assert (a - b).abs().max().item() <= tol * scale * 8, (cfg, (a - b).abs().max().item(), scale)
+
+
+def test_conv_slab_views_f32():
+    """channel-slice views of a wider slab as input and output (dense-block layout)."""
+    hip, emu = pair("f32")
+    g = torch.Generator().manual_seed(4)
+    slab = torch.randn(2, 8, 8, 80, generator=g)
+    w = torch.randn(16 * 9 * 32, generator=g) * 0.1
+    cv = Conv(2, 8, 8, 32, 16)
+    ref = slab.clone()
+    emu.conv_fwd(cv, ref[..., :32], w, ref[..., 32:48], act=0.01)
+    dev = slab.clone().cuda()
+    hip.conv_fwd(cv, dev[..., :32], w.cuda(), dev[..., 32:48], act=0.01)
+    close(dev, ref, "f32", "slab")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,K,O", [(4, 8192, 112), (2, 512, 112), (32, 4096, 112), (4, 128, 16), (33, 1024, 16)])
+def test_linear(dtype, B, K, O):
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(7)
+    x = rnd((B, K), emu.tdtype, g)
+    w = rnd((O, K), emu.tdtype, g, 0.05)
+    y_ref = torch.zeros(B, 128)
+    emu.linear_fwd(x, w, y_ref)
+    y = torch.zeros(B, 128).cuda()
+    hip.linear_fwd(x.cuda(), w.cuda(), y)
+    close(y, y_ref, "f32" if dtype == "f32" else "bf16", "linear_fwd")
+    dy = torch.randn(B, 128, generator=g)
+    mask = rnd((B, K), emu.tdtype, g)
+    for out_dt in ([torch.float32] if dtype == "f32" else [torch.float32, torch.bfloat16]):
+        dx_ref = torch.zeros(B, K, dtype=out_dt)
+        emu.linear_dx(dy, w, dx_ref, mask=mask, mask_slope=0.2)
+        dx = torch.zeros(B, K, dtype=out_dt).cuda()
+        hip.linear_dx(dy.cuda(), w.cuda(), dx, mask=mask.cuda(), mask_slope=0.2)
+        close(dx, dx_ref, dtype, "linear_dx")
+    if B <= 64:
+        dw_ref = torch.randn(O, K, generator=g)
+        dw = dw_ref.clone().cuda()
+        emu.linear_dw(dy, x, dw_ref)
+        hip.linear_dw(dy.cuda(), x.cuda(), dw)
+        close(dw, dw_ref, "f32", "linear_dw")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_elementwise_and_reductions(dtype):
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(8)
+    dt = emu.tdtype
+    B, H, W, Cc = 3, 24, 40, 16
+    a = rnd((B, H, W, Cc), dt, g); b = rnd((B, H, W, Cc), dt, g)
+    slab = rnd((B, H, W, 48), dt, g)
+    # mask_mul on a slab slice
+    ref = slab.clone(); emu.mask_mul(ref[..., 16:32], a, 0.01)
+    dev = slab.clone().cuda(); hip.mask_mul(dev[..., 16:32], a.cuda(), 0.01)
+    close(dev, ref, dtype, "mask_mul")
+    # axpby (incl. in-place and copy)
+    ref = slab.clone(); emu.axpby(ref[..., :16], a, 0.2, b, 1.0)
+    dev = slab.clone().cuda(); hip.axpby(dev[..., :16], a.cuda(), 0.2, b.cuda(), 1.0)
+    close(dev, ref, dtype, "axpby")
+    ref = torch.zeros_like(a); emu.axpby(ref, a, 0.2)
+    dev = torch.zeros_like(a).cuda(); hip.axpby(dev, a.cuda(), 0.2)
+    close(dev, ref, dtype, "axpby copy")
+    # gp interp / sumsq / finish / scale
+    alpha = torch.rand(B, generator=g)
+    ref = torch.zeros_like(a); emu.gp_interp(a, b, alpha, ref)
+    dev = torch.zeros_like(a).cuda(); hip.gp_interp(a.cuda(), b.cuda(), alpha.cuda(), dev)
+    close(dev, ref, dtype, "gp_interp")
+    small = (a.float() * 1e-3).to(dt)
+    ss_ref = torch.zeros(B); emu.sumsq_rows(small, ss_ref)
+    ss = torch.zeros(B).cuda(); hip.sumsq_rows(small.cuda(), ss)
+    assert torch.allclose(ss.cpu(), ss_ref, rtol=1e-5)
+    coef_ref, sc_ref = torch.zeros(B), torch.zeros(1)
+    emu.gp_finish(ss_ref, B, 2 * B, 10.0, 10.0, coef_ref, sc_ref)
+    coef, sc = torch.zeros(B).cuda(), torch.zeros(1).cuda()
+    hip.gp_finish(ss, B, 2 * B, 10.0, 10.0, coef, sc)
+    assert torch.allclose(coef.cpu(), coef_ref, rtol=1e-5) and torch.allclose(sc.cpu(), sc_ref, rtol=1e-5)
+    ref = torch.zeros_like(a); emu.scale_rows(a, coef_ref, ref)
+    dev = torch.zeros_like(a).cuda(); hip.scale_rows(a.cuda(), coef, dev)
+    close(dev, ref, dtype, "scale_rows")
+    # L1 with gradient and addend
+    acc_ref, gr_ref = torch.zeros(1), torch.zeros_like(a)
+    emu.l1(a, b, acc_ref, grad=gr_ref, grad_scale=0.37, addend=slab[..., :16])
+    acc, gr = torch.zeros(1).cuda(), torch.zeros_like(a).cuda()
+    hip.l1(a.cuda(), b.cuda(), acc, grad=gr, grad_scale=0.37, addend=slab.cuda()[..., :16])
+    assert torch.allclose(acc.cpu(), acc_ref, rtol=1e-5)
+    close(gr, gr_ref, dtype, "l1 grad")
+    # colsum: NHWC, 2-D fp32, pixel-shuffled
+    db_ref = torch.randn(Cc, generator=g); db = db_ref.clone().cuda()
+    emu.colsum(a, db_ref); hip.colsum(a.cuda(), db)
+    assert torch.allclose(db.cpu(), db_ref, rtol=1e-4, atol=1e-3)
+    d2 = torch.randn(5, 128, generator=g)
+    db_ref = torch.zeros(128); db = torch.zeros(128).cuda()
+    emu.colsum(d2, db_ref); hip.colsum(d2.cuda(), db)
+    assert torch.allclose(db.cpu(), db_ref, rtol=1e-5, atol=1e-5)
+    db_ref = torch.zeros(4 * Cc); db = torch.zeros(4 * Cc).cuda()
+    emu.colsum_ps(a, db_ref); hip.colsum_ps(a.cuda(), db)
+    assert torch.allclose(db.cpu(), db_ref, rtol=1e-4, atol=1e-3)
+    # head helpers
+    inp = torch.randn(5, 128, generator=g); bias = torch.randn(128, generator=g)
+    for out_dt in (torch.float32, dt):
+        msk = rnd((5, 112), out_dt, g)
+        ref = torch.zeros(5, 112, dtype=out_dt); emu.bias_act(inp, bias, ref, act=0.2)
+        dev = torch.zeros(5, 112, dtype=out_dt).cuda(); hip.bias_act(inp.cuda(), bias.cuda(), dev, act=0.2)
+        close(dev, ref, dtype, "bias_act")
+        ref = torch.zeros(5, 112, dtype=out_dt); emu.bias_act(inp, None, ref, mask=msk, mask_slope=0.2)
+        dev = torch.zeros(5, 112, dtype=out_dt).cuda(); hip.bias_act(inp.cuda(), None, dev, mask=msk.cuda(), mask_slope=0.2)
+        close(dev, ref, dtype, "bias_act mask")
+    out_ref, out = torch.zeros(1), torch.zeros(1).cuda()
+    emu.sum_strided(inp, 5, 128, 0.2, out_ref); hip.sum_strided(inp.cuda(), 5, 128, 0.2, out)
+    assert torch.allclose(out.cpu(), out_ref, rtol=1e-5)
+    buf = torch.zeros(5, 16).cuda(); hip.fill_col(buf, 0, -0.25)
+    assert (buf[:, 0] == -0.25).all() and (buf[:, 1:] == 0).all()
+
+
+def test_adam_and_layout():
+    hip, emu = pair("bf16")
+    g = torch.Generator().manual_seed(9)
+    n = 4096 + 64
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1e-2
+    m, v = torch.zeros(n), torch.zeros(n)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    pd, gd, md, vd = p.cuda(), gr.cuda(), m.cuda(), v.cuda()
+    sh = torch.zeros(n, dtype=torch.bfloat16).cuda()
+    for step in (1, 2, 3):
+        emu.adam(pr, gr, mr, vr, None, 2.5e-4, 0.9, 0.99, 1e-8, step)
+        hip.adam(pd, gd, md, vd, sh, 2.5e-4, 0.9, 0.99, 1e-8, step)
+    assert torch.allclose(pd.cpu(), pr, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(vd.cpu(), vr, rtol=1e-5, atol=1e-12)
+    assert torch.equal(sh.cpu(), pd.cpu().to(torch.bfloat16))
+    x = torch.randn(2, 6, 10, 12, generator=g)
+    for dt in ("f32", "bf16"):
+        h, e = pair(dt)
+        ref = torch.zeros(2, 10, 12, 16, dtype=e.tdtype); e.nchw_to_nhwc(x, ref)
+        dev = torch.ones(2, 10, 12, 16, dtype=e.tdtype).cuda(); h.nchw_to_nhwc(x.cuda(), dev)
+        assert torch.equal(dev.cpu(), ref)
+        back = torch.zeros(2, 6, 10, 12).cuda(); h.nhwc_to_nchw(dev, back)
+        assert torch.equal(back.cpu(), ref[..., :6].float().permute(0, 3, 1, 2))
+        m_ = torch.randn(32 * 9 * 16, generator=g)
+        for kind in (0, 1):
+            ref = torch.zeros(32 * 9 * 16, dtype=e.tdtype); e.repack(m_, ref, 32, 16, kind)
+            dev = torch.zeros(32 * 9 * 16, dtype=e.tdtype).cuda(); h.repack(m_.cuda(), dev, 32, 16, kind)
+            assert torch.equal(dev.cpu(), ref)
