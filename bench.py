@@ -53,34 +53,36 @@ def conv_flops_per_sample(S, F_, cin_p, np_p, nrb, nup=3):
 
 def cpu_baseline(args, wl):
     """The CPU oracle (a port: oracle/ref_step.py, PyTorch-CPU fp32) timed on this box's host cores on a
-    bounded sample of the same workload: ONE critic iteration (+ one generator iteration if time
-    allows) at the workload's tile shapes with batch 1."""
+    BOUNDED sample of the same workload.  The full 128->1024 tile costs ~25 TFLOP per sample-step, minutes
+    per sample on host cores (torch's CPU double-backward of conv runs at ~0.07 TFLOP/s), so the sample is
+    the workload's own networks (same filters / RRDB count) on a tile 4x smaller per side, batch 1: one
+    critic iteration + one generator iteration.  Every conv/linear flop scales with the tile area, so
+    samples/s at the full tile = sample rate / area ratio; this is stated in `sample`."""
     import torch
     from downgan_amd import synthetic
     from oracle import ref_step
     B, S, F_, cin, nrb = wl
+    shrink = 4 if S >= 64 else 1
+    Ss = S // shrink
     cores = os.cpu_count()
     torch.set_num_threads(cores)
     pg = {k: torch.from_numpy(v) for k, v in synthetic.generator_params(F_, cin, 2, nrb).items()}
-    pc = {k: torch.from_numpy(v) for k, v in synthetic.critic_params(F_, 8 * S, 2).items()}
+    pc = {k: torch.from_numpy(v) for k, v in synthetic.critic_params(F_, 8 * Ss, 2).items()}
     tr = ref_step.OracleTrainer(pg, pc, ref_step.HP(batch_size=1), num_res_blocks=nrb)
-    coarse, fine = synthetic.tiles(1, cin, S)
+    coarse, fine = synthetic.tiles(1, cin, Ss)
     coarse, fine = torch.from_numpy(coarse), torch.from_numpy(fine)
     alpha = torch.from_numpy(synthetic.alpha(1, 0))
     t0 = time.perf_counter()
     tr.critic_iteration(coarse, fine, alpha)
     tc = time.perf_counter() - t0
-    gf, cf = conv_flops_per_sample(S, F_, cin, 2, nrb)
-    if tc < 25.0:
-        t0 = time.perf_counter()
-        tr.generator_iteration(coarse, fine)
-        tg = time.perf_counter() - t0
-        sample = f"1 critic + 1 generator iteration, batch 1, {cin}ch {S}x{S}->{8 * S}x{8 * S}, F={F_}, fp32, measured {tc:.1f}s + {tg:.1f}s"
-    else:
-        tg = tc * (3 * gf + 2 * cf) / (gf + 10 * cf)
-        sample = (f"1 critic iteration, batch 1, {cin}ch {S}x{S}->{8 * S}x{8 * S}, F={F_}, fp32, measured {tc:.1f}s; "
-                  f"generator iteration extrapolated by flop ratio to {tg:.1f}s")
-    return {"value": 1.0 / (tc + tg / 5.0), "unit": "samples/s", "cores": cores, "kind": "port", "sample": sample}
+    t0 = time.perf_counter()
+    tr.generator_iteration(coarse, fine)
+    tg = time.perf_counter() - t0
+    area = shrink * shrink
+    sample = (f"oracle port, batch 1, {cin}ch {Ss}x{Ss}->{8 * Ss}x{8 * Ss} tile with the workload's networks (F={F_}, {nrb} RRDBs), "
+              f"fp32: 1 critic iteration {tc:.1f}s + 1 generator iteration {tg:.1f}s; step time = critic + generator/5; "
+              f"scaled by the tile-area ratio {area}x to the {S}->{8 * S} tile (all conv/linear flops scale with area)")
+    return {"value": 1.0 / ((tc + tg / 5.0) * area), "unit": "samples/s", "cores": cores, "kind": "port", "sample": sample}
 
 
 def main():

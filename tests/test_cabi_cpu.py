@@ -1,0 +1,54 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/downgan_hip.h
+declares; host-side argument validation returns dg_status codes (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+from downgan_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, "include", "downgan_hip.h")) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert set(_lib.EXPORTS) == set(syms), set(_lib.EXPORTS) ^ set(syms)
+    assert b"gfx950" in lib.dg_version()
+
+
+def test_planner_rejects_bad_geometry():
+    lib = _lib.lib()
+    d = (_lib.GGDesc * 4)()
+    ok = _lib.ConvGeom(dtype=_lib.DG_BF16, N=1, H=8, W=8, Cin=16, Cout=16, stride=1, pixel_shuffle=0, ldx=16, ldy=16)
+    assert lib.dg_conv3x3_plan(C.byref(ok), 0, d) == 1
+    assert lib.dg_conv3x3_plan(C.byref(ok), 1, d) == 1
+    bad = [dict(stride=3), dict(Cin=12), dict(Cout=8), dict(dtype=7), dict(H=7, stride=2), dict(pixel_shuffle=1, Cout=32)]
+    for kw in bad:
+        g = _lib.ConvGeom(dtype=_lib.DG_BF16, N=1, H=8, W=8, Cin=16, Cout=16, stride=1, pixel_shuffle=0, ldx=16, ldy=16)
+        for k, v in kw.items():
+            setattr(g, k, v)
+        assert lib.dg_conv3x3_plan(C.byref(g), 0, d) < 0, kw
+    assert lib.dg_conv3x3_plan(C.byref(ok), 2, d) < 0
+    # stride-2 data gradient = 4 parity classes with 1/2/2/4 taps (no zero insertion)
+    s2 = _lib.ConvGeom(dtype=_lib.DG_F32, N=1, H=8, W=8, Cin=16, Cout=32, stride=2, pixel_shuffle=0, ldx=16, ldy=32)
+    assert lib.dg_conv3x3_plan(C.byref(s2), 1, d) == 4
+    assert sorted(d[i].ntaps for i in range(4)) == [1, 2, 2, 4]
+
+
+def test_null_and_shape_errors_do_not_launch():
+    lib = _lib.lib()
+    g = _lib.ConvGeom(dtype=_lib.DG_BF16, N=1, H=8, W=8, Cin=16, Cout=16, stride=1, pixel_shuffle=0, ldx=16, ldy=16)
+    assert lib.dg_conv3x3_fwd(C.byref(g), None, None, None, None, None) == -3     # DG_ERR_BAD_ARG
+    assert lib.dg_conv3x3_wgrad(C.byref(g), None, None, None, None) == -3
+    assert lib.dg_linear_fwd(_lib.DG_BF16, None, 0, None, 0, None, 0, 1, 16, 32, None) == -3
+    assert lib.dg_adam(None, None, None, None, None, 16, 1e-3, 0.9, 0.99, 1e-8, 1, 1.0, None) == -3
