@@ -19,6 +19,8 @@
 // channels of one pixel in the accumulator, so the epilogue loads/stores 8-16 B vectors.
 #include "dg_internal.h"
 
+#include <stdlib.h>
+
 struct GGArgs {
   const void* x; const void* w; void* y;
   const float* bias; const void* r1; const void* r2; const void* mask;
@@ -48,6 +50,68 @@ template <> struct Mma<float> {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
   }
 };
+
+template <typename T, int BP, int BC, int WP, int WC>
+__device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC / 16][WP / 16], int p0, int c0, int wp, int wc,
+                                            int l15, int g) {
+  constexpr int FP = WP / 16, FC = WC / 16;
+  // ---- epilogue: lane owns channels co0..co0+3 of pixel m for each (j,i) fragment
+  T* Y = reinterpret_cast<T*>(a.y);
+  const T* R1 = reinterpret_cast<const T*>(a.r1);
+  const T* R2 = reinterpret_cast<const T*>(a.r2);
+  const T* MK = reinterpret_cast<const T*>(a.mask);
+#pragma unroll
+  for (int i = 0; i < FP; ++i) {
+    const int m = p0 + wp * WP + 16 * i + l15;
+    if (m >= a.M) continue;
+    const int gx = m % a.Wg, t = m / a.Wg;
+    const int gy = t % a.Hg, n = t / a.Hg;
+#pragma unroll
+    for (int j = 0; j < FC; ++j) {
+      const int co0 = c0 + wc * WC + 16 * j + 4 * g;
+      if (co0 >= a.Nout) continue;
+      int py, px, c;
+      if (a.dst_ps) {
+        const int q = co0 / a.cps_dst;
+        c = co0 - q * a.cps_dst;
+        py = gy * 2 + (q >> 1); px = gx * 2 + (q & 1);
+      } else {
+        c = co0; py = gy * a.dy_mul + a.dy_off; px = gx * a.dx_mul + a.dx_off;
+      }
+      const long long pix = ((long long)n * a.Hd + py) * a.Wd + px;
+      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+      if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + co0);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (a.has_act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], a.act_slope);
+      }
+      if (R1) {
+        float r[4]; ld4(R1 + pix * a.ldr1 + c, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s1 + r[e];
+      }
+      if (R2) {
+        float r[4]; ld4(R2 + pix * a.ldr2 + c, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
+      }
+      if (MK) {
+        float r[4]; ld4(MK + pix * a.ldmask + c, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
+      }
+      if (a.accumulate) {
+        float r[4]; ld4(Y + pix * a.ldy + c, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      st4(Y + pix * a.ldy + c, v);
+    }
+  }
+}
 
 template <typename T, int BP, int BC, int WP, int WC>
 __global__ __launch_bounds__(256) void gg_kernel(const GGArgs a) {
@@ -171,62 +235,153 @@ __global__ __launch_bounds__(256) void gg_kernel(const GGArgs a) {
     cur ^= 1;
   }
 
-  // ---- epilogue: lane owns channels co0..co0+3 of pixel m for each (j,i) fragment
-  T* Y = reinterpret_cast<T*>(a.y);
-  const T* R1 = reinterpret_cast<const T*>(a.r1);
-  const T* R2 = reinterpret_cast<const T*>(a.r2);
-  const T* MK = reinterpret_cast<const T*>(a.mask);
+  gg_epilogue<T, BP, BC, WP, WC>(a, acc, p0, c0, wp, wc, l15, g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: every K-step (8 chunks) lies inside ONE tap (chunks-per-tap % 8 == 0, true for every
+// wide layer: Cred >= 64 bf16 / 32 fp32).  Then tap, channel offset and the source-pixel shift are
+// workgroup-uniform per K-step and live in SGPRs; each thread keeps constant 32-bit byte offsets for
+// its rows and a 9-bit tap-validity mask.  Operands are fetched with raw buffer loads whose
+// descriptor base is re-pointed per K-step (scalar adds); a padded / out-of-tile row simply gets an
+// out-of-range offset and the hardware returns zeros - no per-row address arithmetic in the loop.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#define DG_OOB_OFF 0x80000000u
+
+template <typename T, int BP, int BC, int WP, int WC>
+__global__ __launch_bounds__(256) void gg_fast_kernel(const GGArgs a) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int NPW = BP / WP;
+  constexpr int FP = WP / 16, FC = WC / 16;
+  constexpr int PR = BP / 32;
+  constexpr int CR = (BC + 31) / 32;
+  constexpr int ROWS = BP + BC;
+  static_assert((BP / WP) * (BC / WC) == 4, "4 waves per workgroup");
+  __shared__ uint4 smem[2 * ROWS * 8];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tile_c = tile % a.nct, tile_p = tile / a.nct;
+  const int p0 = tile_p * BP, c0 = tile_c * BC;
+  const int cc = tid & 7, r0 = tid >> 3;
+  const int Wsrc = a.src_ps ? 2 * a.Ws : a.Ws, Hsrc = a.src_ps ? 2 * a.Hs : a.Hs, psm = a.src_ps ? 2 : 1;
+
+  // workgroup-uniform base pixel: first row of the tile minus a margin that covers every tap shift
+  long long pbase;
+  {
+    const int gx = p0 % a.Wg, t = p0 / a.Wg;
+    const int gy = t % a.Hg, im = t / a.Hg;
+    pbase = ((long long)im * Hsrc + (long long)gy * a.sy_mul * psm) * Wsrc + (long long)gx * a.sx_mul * psm - (2 * Wsrc + 2);
+    if (pbase < 0) pbase = 0;
+  }
+  unsigned rowoff[PR], vmask[PR];
 #pragma unroll
-  for (int i = 0; i < FP; ++i) {
-    const int m = p0 + wp * WP + 16 * i + l15;
-    if (m >= a.M) continue;
-    const int gx = m % a.Wg, t = m / a.Wg;
-    const int gy = t % a.Hg, n = t / a.Hg;
-#pragma unroll
-    for (int j = 0; j < FC; ++j) {
-      const int co0 = c0 + wc * WC + 16 * j + 4 * g;
-      if (co0 >= a.Nout) continue;
-      int py, px, c;
-      if (a.dst_ps) {
-        const int q = co0 / a.cps_dst;
-        c = co0 - q * a.cps_dst;
-        py = gy * 2 + (q >> 1); px = gx * 2 + (q & 1);
-      } else {
-        c = co0; py = gy * a.dy_mul + a.dy_off; px = gx * a.dx_mul + a.dx_off;
+  for (int i = 0; i < PR; ++i) {
+    const int m = p0 + r0 + 32 * i;
+    rowoff[i] = 0; vmask[i] = 0;
+    if (m < a.M) {
+      const int gx = m % a.Wg, t = m / a.Wg;
+      const int gy = t % a.Hg, im = t / a.Hg;
+      const int sy0 = gy * a.sy_mul, sx0 = gx * a.sx_mul;
+      const long long p = ((long long)im * Hsrc + (long long)sy0 * psm) * Wsrc + (long long)sx0 * psm;
+      rowoff[i] = (unsigned)((p - pbase) * a.ldx * ES) + cc * 16;
+      for (int t2 = 0; t2 < a.ntaps; ++t2) {
+        const unsigned code = t2 < 8 ? (unsigned)((a.tap_lo >> (8 * t2)) & 0xffull) : (a.tap_hi & 0xffu);
+        const int sy = sy0 + (int)(code & 3u) - 1, sx = sx0 + (int)((code >> 2) & 3u) - 1;
+        if ((unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws) vmask[i] |= 1u << t2;
       }
-      const long long pix = ((long long)n * a.Hd + py) * a.Wd + px;
-      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-      if (a.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + co0);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (a.has_act) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], a.act_slope);
-      }
-      if (R1) {
-        float r[4]; ld4(R1 + pix * a.ldr1 + c, r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s1 + r[e];
-      }
-      if (R2) {
-        float r[4]; ld4(R2 + pix * a.ldr2 + c, r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
-      }
-      if (MK) {
-        float r[4]; ld4(MK + pix * a.ldmask + c, r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
-      }
-      if (a.accumulate) {
-        float r[4]; ld4(Y + pix * a.ldy + c, r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += r[e];
-      }
-      st4(Y + pix * a.ldy + c, v);
     }
   }
+  unsigned woff[CR];
+#pragma unroll
+  for (int i = 0; i < CR; ++i) {
+    const int row = r0 + 32 * i;
+    woff[i] = (row < BC && c0 + row < a.Nout) ? (unsigned)((long long)row * a.ldw * ES) + cc * 16 : DG_OOB_OFF;
+  }
+  const char* Xb = reinterpret_cast<const char*>(a.x) + pbase * a.ldx * ES;
+  const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
+
+  u32x4_t ra[PR], rb[CR];
+  int tap = 0, cbase = 0;          // workgroup-uniform K position (SGPRs)
+  auto gload = [&]() {
+    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
+    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1, ws = (int)(code >> 4);
+    long long xo;
+    if (!a.src_ps) xo = ((long long)dy * a.Ws + dx) * a.ldx + cbase * EPC;
+    else {
+      const int q = cbase / a.cps_src_chunks, cq = cbase - q * a.cps_src_chunks;
+      xo = ((long long)(2 * dy + (q >> 1)) * Wsrc + (2 * dx + (q & 1))) * a.ldx + cq * EPC;
+    }
+    const long long wo = (long long)ws * a.Cred + cbase * EPC;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + xo * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + wo * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      const unsigned vo = ((vmask[i] >> tap) & 1u) ? rowoff[i] : DG_OOB_OFF;
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < CR; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[i], 0, 0);
+    cbase += 8;
+    if (cbase >= a.cch) { cbase = 0; ++tap; }
+  };
+  auto lstore = [&](int buf) {
+    uint4* s = smem + buf * ROWS * 8;
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      const int row = r0 + 32 * i;
+      s[row * 8 + (cc ^ ((row >> 1) & 7))] = __builtin_bit_cast(uint4, ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < CR; ++i) {
+      const int row = r0 + 32 * i;
+      if (row < BC) s[(BP + row) * 8 + (cc ^ ((row >> 1) & 7))] = __builtin_bit_cast(uint4, rb[i]);
+    }
+  };
+
+  f32x4_t acc[FC][FP];
+#pragma unroll
+  for (int j = 0; j < FC; ++j)
+#pragma unroll
+    for (int i = 0; i < FP; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int wp = wave % NPW, wc = wave / NPW;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nk = a.kchunks >> 3;
+
+  gload();
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int ks = 0; ks < nk; ++ks) {
+    const bool more = ks + 1 < nk;
+    if (more) gload();
+    const uint4* s = smem + cur * ROWS * 8;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = kk * 4 + g;
+      uint4 fa[FC], fb[FP];
+#pragma unroll
+      for (int j = 0; j < FC; ++j) {
+        const int row = wc * WC + 16 * j + l15;
+        fa[j] = s[(BP + row) * 8 + (ch ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < FP; ++i) {
+        const int row = wp * WP + 16 * i + l15;
+        fb[i] = s[row * 8 + (ch ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < FC; ++j)
+#pragma unroll
+        for (int i = 0; i < FP; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  gg_epilogue<T, BP, BC, WP, WC>(a, acc, p0, c0, wp, wc, l15, g);
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -259,7 +414,11 @@ static int gg_launch_t(GGArgs& a, hipStream_t st) {
   a.nct = (unsigned)((a.Nout + BC - 1) / BC);
   const unsigned npt = (unsigned)((a.M + BP - 1) / BP);
   a.nwg = a.nct * npt;
-  hipLaunchKernelGGL((gg_kernel<T, BP, BC, WP, WC>), dim3(a.nwg), dim3(256), 0, st, a);
+  static const bool force_generic = getenv("DG_GG_GENERIC") != nullptr;
+  if (a.cch % 8 == 0 && (!a.src_ps || a.cps_src_chunks % 8 == 0) && !force_generic)
+    hipLaunchKernelGGL((gg_fast_kernel<T, BP, BC, WP, WC>), dim3(a.nwg), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((gg_kernel<T, BP, BC, WP, WC>), dim3(a.nwg), dim3(256), 0, st, a);
   return dg_check_launch();
 }
 
