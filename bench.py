@@ -51,6 +51,22 @@ def conv_flops_per_sample(S, F_, cin_p, np_p, nrb, nup=3):
     return gf, cf
 
 
+def host_cores():
+    """CPUs this process may actually use: min(os.cpu_count, affinity mask, cgroup v2 cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(args, wl):
     """The CPU oracle (a port: oracle/ref_step.py, PyTorch-CPU fp32) timed on this box's host cores on a
     BOUNDED sample of the same workload.  The full 128->1024 tile costs ~25 TFLOP per sample-step, minutes
@@ -64,7 +80,7 @@ def cpu_baseline(args, wl):
     B, S, F_, cin, nrb = wl
     shrink = 4 if S >= 64 else 1
     Ss = S // shrink
-    cores = os.cpu_count()
+    cores = host_cores()
     torch.set_num_threads(cores)
     pg = {k: torch.from_numpy(v) for k, v in synthetic.generator_params(F_, cin, 2, nrb).items()}
     pc = {k: torch.from_numpy(v) for k, v in synthetic.critic_params(F_, 8 * Ss, 2).items()}
