@@ -71,14 +71,14 @@ def cpu_baseline(args, wl):
     """The CPU oracle (a port: oracle/ref_step.py, PyTorch-CPU fp32) timed on this box's host cores on a
     BOUNDED sample of the same workload.  The full 128->1024 tile costs ~25 TFLOP per sample-step, minutes
     per sample on host cores (torch's CPU double-backward of conv runs at ~0.07 TFLOP/s), so the sample is
-    the workload's own networks (same filters / RRDB count) on a tile 4x smaller per side, batch 1: one
+    the workload's own networks (same filters / RRDB count) on a tile 2x smaller per side, batch 1: one
     critic iteration + one generator iteration.  Every conv/linear flop scales with the tile area, so
     samples/s at the full tile = sample rate / area ratio; this is stated in `sample`."""
     import torch
     from downgan_amd import synthetic
     from oracle import ref_step
     B, S, F_, cin, nrb = wl
-    shrink = 4 if S >= 64 else 1
+    shrink = 2 if S >= 64 else 1
     Ss = S // shrink
     cores = host_cores()
     torch.set_num_threads(cores)

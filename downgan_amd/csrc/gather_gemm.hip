@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void gg_dma_kernel(const GGArgs a) {
 // weights stream per tap-step.  Per 9 tap-steps: 41 KB patch + 144 KB weights for 2x the flops of the
 // per-tap kernel's 288 KB -> 3.1x fewer bytes through the vector-memory path per flop, and the patch of
 // the NEXT channel block has a whole 9-step window to arrive.
-template <typename T>
+template <typename T, int ABL = 0>   // ABL: timing-only ablations (1 = no MFMA, 2 = no global loads/LDS stores, 3 = no fragment reads)
 __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_x, int tiles_y) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int ES = (int)sizeof(T);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
   constexpr int NPL = (PROWS * 8 + 511) / 512;                           // 6 patch chunks per thread
   extern __shared__ __attribute__((aligned(16))) uint4 dsm[];
   uint4* const s_patch = dsm;                   // [2][PROWS][8]
-  uint4* const s_w = dsm + 2 * PROWS * 8;       // [2][BC][8]
+  uint4* const s_w = dsm + 2 * PROWS * 8;       // [3][BC][8]: weights are fetched TWO tap-steps ahead
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
   const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
   const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
 
-  u32x4_t rp[NPL], rw[2];
+  u32x4_t rp[NPL], rwa[2], rwb[2];
   auto load_patch = [&](int cb) {
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * 8 * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
 #pragma unroll
@@ -579,14 +579,14 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
       if (pr < PROWS) s[pr * 8 + (cc ^ ((pr >> 1) & 7))] = __builtin_bit_cast(uint4, rp[i]);
     }
   };
-  auto load_w = [&](int cb, int tap) {
+  auto load_w = [&](u32x4_t (&rw)[2], int cb, int tap) {
     const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
     const long long wo = (long long)(code >> 4) * a.Cred + cb * 8 * EPC;
     __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + wo * ES), 0, (int)DG_OOB_OFF, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 2; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rwd, woff[i], 0, 0);
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](const u32x4_t (&rw)[2], int buf) {
     uint4* s = s_w + buf * BC * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -606,49 +606,84 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
   const int ncb = a.cch >> 3, ntaps = a.ntaps;
   const int nsteps = ncb * ntaps;
 
-  load_patch(0);
-  load_w(0, 0);
-  store_patch(0);
-  store_w(0);
-  __syncthreads();
-
-  int cb = 0, tap = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    const bool more = s + 1 < nsteps;
-    int ntap = tap + 1, ncbn = cb;
-    if (ntap == ntaps) { ntap = 0; ncbn = cb + 1; }
-    if (more) load_w(ncbn, ntap);
-    const bool next_cb = tap == 0 && cb + 1 < ncb;
-    if (next_cb) load_patch(cb + 1);
-
-    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
+  // (cb, tap) of a tap-step, advanced incrementally
+  auto advance = [&](int& cbx, int& tapx) { if (++tapx == ntaps) { tapx = 0; ++cbx; } };
+  // Fragment reads of one K-half (kk) of tap-step (cbx, tapx) whose weights sit in ring slot wbx.
+  auto read_frags = [&](uint4 (&fa)[4], uint4 (&fb)[4], int cbx, int tapx, int wbx, int kk) {
+    const unsigned code = tapx < 8 ? (unsigned)((a.tap_lo >> (8 * tapx)) & 0xffull) : (a.tap_hi & 0xffu);
     const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
-    const uint4* sp = s_patch + (cb & 1) * PROWS * 8;
-    const uint4* sw = s_w + (s & 1) * BC * 8;
+    const uint4* sp = s_patch + (cbx & 1) * PROWS * 8;
+    const uint4* sw = s_w + wbx * BC * 8;
     const int prow0 = (wp * 4 + 1 + dy) * PW + 1 + dx + l15;   // patch row of this lane's pixel in tile row wp*4
+    const int ch = kk * 4 + g;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ch = kk * 4 + g;
-      uint4 fa[4], fb[4];
+    for (int j = 0; j < 4; ++j) {
+      const int row = wc * 64 + 16 * j + l15;
+      if ((ABL == 3 || ABL == 4)) fa[j] = make_uint4(row, ch, tapx, 1); else
+      fa[j] = sw[row * 8 + (ch ^ ((row >> 1) & 7))];
+    }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wc * 64 + 16 * j + l15;
-        fa[j] = sw[row * 8 + (ch ^ ((row >> 1) & 7))];
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int pr = prow0 + i * PW;
+      if ((ABL == 3 || ABL == 4)) fb[i] = make_uint4(pr, ch, tapx, 2); else
+      fb[i] = sp[pr * 8 + (ch ^ ((pr >> 1) & 7))];
+    }
+  };
+  auto mma_block = [&](const uint4 (&fa)[4], const uint4 (&fb)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int pr = prow0 + i * PW;
-        fb[i] = sp[pr * 8 + (ch ^ ((pr >> 1) & 7))];
+        if (ABL == 1) { asm volatile("" :: "v"(fa[j].x), "v"(fb[i].x)); }
+        else Mma<T>::run(fa[j], fb[i], acc[j][i]);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
-    }
-    if (more) store_w((s + 1) & 1);
-    if (tap == ntaps - 1 && cb + 1 < ncb) store_patch((cb + 1) & 1);
+  };
+
+  // Software pipeline (weights ring of 3 LDS slots, fragments double-buffered in registers):
+  //   step s:  read F1 <- (s, kk=1) | MFMA on F0 = (s, kk=0) | read F0 <- (s+1, kk=0) | MFMA on F1
+  //            | store weights(s+2) (fetched during step s-1) | barrier
+  // so every LDS fragment read is in flight behind a 16-MFMA block, and the weights of step s+1 are
+  // already visible (stored during step s-1) when their first fragments are read before the barrier.
+  load_patch(0);
+  load_w(rwa, 0, 0);
+  store_patch(0);
+  store_w(rwa, 0);
+  int cbn = 0, tapn = 0;           // running position used for the prologue / look-ahead loads
+  advance(cbn, tapn);
+  if (nsteps > 1) { load_w(rwa, cbn, tapn); store_w(rwa, 1); }          // step 1 -> slot 1
+  int cb1 = cbn, tap1 = tapn;      // position of step s+1
+  advance(cbn, tapn);
+  if (nsteps > 2) load_w(rwa, cbn, tapn);                              // step 2 -> rwa (stored at the end of step 0)
+  advance(cbn, tapn);              // cbn/tapn = position of step s+3
+  __syncthreads();
+
+  uint4 fa0[4], fb0[4], fa1[4], fb1[4];
+  int cb = 0, tap = 0, wb = 0;     // wb = s % 3
+  read_frags(fa0, fb0, 0, 0, 0, 0);
+  // `rst` holds weights of step s+2 (fetched during step s-1); `rld` receives step s+3.
+  auto step = [&](int s, u32x4_t (&rst)[2], u32x4_t (&rld)[2]) {
+    if ((ABL != 2 && ABL != 4) && s + 3 < nsteps) load_w(rld, cbn, tapn);
+    if ((ABL != 2 && ABL != 4) && tap == 0 && cb + 1 < ncb) load_patch(cb + 1);
+    const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;
+    read_frags(fa1, fb1, cb, tap, wb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_block(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < nsteps) read_frags(fa0, fb0, cb1, tap1, wb1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_block(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if ((ABL != 2 && ABL != 4) && s + 2 < nsteps) store_w(rst, wb2);
+    if ((ABL != 2 && ABL != 4) && cb + 1 < ncb && tap == (ntaps >= 2 ? ntaps - 2 : 0)) store_patch((cb + 1) & 1);
     __syncthreads();
-    tap = ntap; cb = ncbn;
+    wb = wb1;
+    advance(cb, tap);
+    advance(cb1, tap1);
+    advance(cbn, tapn);
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, rwa, rwb);
+    if (s + 1 < nsteps) step(s + 1, rwb, rwa);
   }
 
 #pragma unroll
@@ -666,17 +701,34 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
 
 template <typename T>
 static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
-  constexpr int LDS_BYTES = (2 * 324 + 2 * 128) * 8 * 16;
+  constexpr int LDS_BYTES = (2 * 324 + 3 * 128) * 8 * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return DG_ERR_LAUNCH;
     attr_set = true;
   }
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
   a.nct = (unsigned)((a.Nout + 127) / 128);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
-  hipLaunchKernelGGL((gg_halo_kernel<T>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+  static const int abl = getenv("DG_ABL") ? atoi(getenv("DG_ABL")) : 0;
+  if (abl) {   // timing-only diagnostic builds (wrong results by construction)
+    static bool abl_set = false;
+    if (!abl_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      abl_set = true;
+    }
+    if (abl == 4) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipLaunchKernelGGL((gg_halo_kernel<T, 4>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+    } else if (abl == 1) hipLaunchKernelGGL((gg_halo_kernel<T, 1>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+    else if (abl == 2) hipLaunchKernelGGL((gg_halo_kernel<T, 2>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((gg_halo_kernel<T, 3>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+    return dg_check_launch();
+  }
+  hipLaunchKernelGGL((gg_halo_kernel<T, 0>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
   return dg_check_launch();
 }
 
@@ -726,7 +778,7 @@ template <typename T>
 static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   static const bool no_halo = getenv("DG_GG_NOHALO") != nullptr;
   // the patch is sized for tap shifts in [-1, 1] around a unit-stride grid (stride-1 forward, all data gradients)
-  if (!no_halo && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 &&
+  if (!no_halo && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 &&
       a.Hs == a.Hg && a.Ws == a.Wg)
     return gg_launch_halo<T>(a, N, st);
   if (a.Nout > 64) return gg_launch_t<T, 128, 128, 64, 64>(a, st);

@@ -29,10 +29,13 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
+    ap.add_argument("--layers", default="", help="comma-separated substrings of layer names to run")
     args = ap.parse_args()
     o = HipOps(args.dtype)
     g = torch.Generator().manual_seed(0)
     for name, N, H, ci, co, st, ps in LAYERS:
+        if args.layers and not any(k in name for k in args.layers.split(',')):
+            continue
         cv = Conv(N, H, H, ci, co, st, ps)
         x = torch.randn(N, H, H, ci, generator=g).to(o.tdtype).cuda()
         w = (torch.randn(co * 9 * ci, generator=g) * 0.05).to(o.tdtype).cuda()
