@@ -11,6 +11,8 @@
 // wave-instruction adds two full 128-B row segments (the full-rate shape for float atomics).
 #include "dg_internal.h"
 
+#include <stdlib.h>
+
 struct WGArgs {
   const void* x; const void* u; float* dw;
   long long ldx, ldu;
@@ -22,7 +24,13 @@ struct WGArgs {
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
-template <typename T, int BCO, int BCI>
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4w_t;
+#define WG_OOB_OFF 0x80000000u
+
+// ROWSTEP: Wo % KP == 0, so every K-step (KP consecutive output pixels) lies inside ONE output row: image / row
+// / first column are workgroup-uniform scalars and each thread's byte offsets are loop constants (raw buffer
+// loads, out-of-image taps get an out-of-range offset and read zeros).
+template <typename T, int BCO, int BCI, bool ROWSTEP>
 __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int KP = 32;                         // pixels per K-step
@@ -45,33 +53,98 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
   const T* __restrict__ U = reinterpret_cast<const T*>(a.u);
 
   uint4 ru[NU], rx[NX];
-  auto gload = [&](int pb) {
+  // ---- ROWSTEP state: scalar position of the current K-step and constant per-thread offsets
+  int s_n = 0, s_ho = 0, s_wo = 0;
+  unsigned uoffc[NU], xoffc[NX];
+  int xrow[NX];
+  if constexpr (ROWSTEP) {
+    s_wo = pbeg % a.Wo; const int t = pbeg / a.Wo; s_ho = t % a.Ho; s_n = t / a.Ho;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int e = tid + 256 * i, row = e / CPRU, col = e % CPRU;
+      const int co = co0 + col * EPC;
+      if (co >= a.Cout) { uoffc[i] = WG_OOB_OFF; continue; }
+      if (!a.u_ps) uoffc[i] = (unsigned)(((long long)row * a.ldu + co) * (int)sizeof(T));
+      else {
+        const int cchunk = co / EPC, q = cchunk / a.cps_chunks, c = cchunk - q * a.cps_chunks;
+        uoffc[i] = (unsigned)((((long long)(q >> 1) * (2 * a.Wo) + 2 * row + (q & 1)) * a.ldu + c * EPC) * (int)sizeof(T));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 256 * i, row = e / CPRX, col = e % CPRX;
+      const int ci = ci0 + col * EPC;
+      xrow[i] = row;
+      xoffc[i] = ci < a.Cin ? (unsigned)(((long long)row * a.stride * a.ldx + ci) * (int)sizeof(T)) : WG_OOB_OFF;
+    }
+  }
+  auto gload_row = [&]() {
+    // scalar bases of this K-step
+    const long long ub = !a.u_ps ? ((long long)(s_n * a.Ho + s_ho) * a.Wo + s_wo) * a.ldu
+                                 : ((long long)(s_n * 2 * a.Ho + 2 * s_ho) * (2 * a.Wo) + 2 * s_wo) * a.ldu;
+    const int hi = s_ho * a.stride + dr;
+    const bool row_ok = (unsigned)hi < (unsigned)a.H;
+    const int wi0 = s_wo * a.stride + dc;
+    const long long xb = ((long long)(s_n * a.H + hi) * a.W + wi0) * a.ldx;
+    __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)(U + ub), 0, (int)WG_OOB_OFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xb), 0, (int)WG_OOB_OFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) ru[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rU, uoffc[i], 0, 0));
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int wi = wi0 + xrow[i] * a.stride;
+      const unsigned vo = (row_ok && (unsigned)wi < (unsigned)a.W) ? xoffc[i] : WG_OOB_OFF;
+      rx[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, vo, 0, 0));
+    }
+    s_wo += KP;
+    if (s_wo >= a.Wo) { s_wo = 0; if (++s_ho == a.Ho) { s_ho = 0; ++s_n; } }
+  };
+  // Each thread owns NU chunks of the adjoint tile and NX chunks of the input tile; chunk e = tid + 256*i is
+  // (row = e / chunks_per_row, col = e % chunks_per_row).  The pixel coordinates of every owned row are
+  // tracked INCREMENTALLY (the K loop advances by KP pixels per step), so the loop has no integer division.
+  int un[NU], uho[NU], uwo[NU];       // (image, ho, wo) of the adjoint rows (only needed for the shuffled layout)
+  int xn[NX], xho[NX], xwo[NX];
+  auto init_pos = [&](int p, int& n, int& ho, int& wo) {
+    wo = p % a.Wo; const int t = p / a.Wo; ho = t % a.Ho; n = t / a.Ho;
+  };
+  auto advance_pos = [&](int& n, int& ho, int& wo) {
+    wo += KP;
+    while (wo >= a.Wo) { wo -= a.Wo; if (++ho == a.Ho) { ho = 0; ++n; } }
+  };
+#pragma unroll
+  for (int i = 0; i < NU; ++i) init_pos(pbeg + (tid + 256 * i) / CPRU, un[i], uho[i], uwo[i]);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) init_pos(pbeg + (tid + 256 * i) / CPRX, xn[i], xho[i], xwo[i]);
+  auto gload_gen = [&](int pb) {
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const int e = tid + 256 * i, row = e / CPRU, col = e % CPRU;
       const int p = pb + row, co = co0 + col * EPC;
-      bool ok = p < pend && co < a.Cout;
+      const bool ok = p < pend && co < a.Cout;
       long long off;
       if (!a.u_ps) off = (long long)p * a.ldu + co;
       else {
-        const int wo = p % a.Wo, t = p / a.Wo, ho = t % a.Ho, n = t / a.Ho;
         const int cchunk = co / EPC, q = cchunk / a.cps_chunks, c = cchunk - q * a.cps_chunks;
-        off = (((long long)(n * 2 * a.Ho + 2 * ho + (q >> 1))) * (2 * a.Wo) + 2 * wo + (q & 1)) * a.ldu + c * EPC;
+        off = (long long)(((un[i] * 2 * a.Ho + 2 * uho[i] + (q >> 1))) * (2 * a.Wo) + 2 * uwo[i] + (q & 1)) * a.ldu + c * EPC;
       }
       uint4 v = *reinterpret_cast<const uint4*>(U + (ok ? off : 0ll));
       ru[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+      advance_pos(un[i], uho[i], uwo[i]);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int e = tid + 256 * i, row = e / CPRX, col = e % CPRX;
       const int p = pb + row, ci = ci0 + col * EPC;
-      const int wo = p % a.Wo, t = p / a.Wo, ho = t % a.Ho, n = t / a.Ho;
-      const int hi = ho * a.stride + dr, wi = wo * a.stride + dc;
+      const int hi = xho[i] * a.stride + dr, wi = xwo[i] * a.stride + dc;
       const bool ok = p < pend && ci < a.Cin && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      const long long off = ((long long)(n * a.H + hi) * a.W + wi) * a.ldx + ci;
+      const long long off = (long long)((xn[i] * a.H + hi) * a.W + wi) * a.ldx + ci;
       uint4 v = *reinterpret_cast<const uint4*>(X + (ok ? off : 0ll));
       rx[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+      advance_pos(xn[i], xho[i], xwo[i]);
     }
+  };
+  auto gload = [&](int pb) {
+    if constexpr (ROWSTEP) gload_row(); else gload_gen(pb);
   };
   auto lstore = [&](int buf) {
     T* su = smem + buf * KP * (BCO + BCI);
@@ -184,17 +257,26 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   const int nco_t = (a.Cout + bco - 1) / bco;
   a.nci_t = (a.Cin + bci - 1) / bci;
   const int ntiles = nco_t * 9 * a.nci_t;
-  int splits = (2048 + ntiles - 1) / ntiles;
+  static const int target_blocks = getenv("DG_WG_BLOCKS") ? atoi(getenv("DG_WG_BLOCKS")) : 2304;   // 3 resident workgroups x 256 CUs x 3 rounds
+  int splits = (target_blocks + ntiles - 1) / ntiles;
   const int max_splits = (a.Mpix + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   a.ppb = ((a.Mpix + splits - 1) / splits + 31) / 32 * 32;
   splits = (a.Mpix + a.ppb - 1) / a.ppb;
   dim3 grid(ntiles, splits);
-  if (big_co && big_ci) hipLaunchKernelGGL((wg_kernel<T, 128, 128>), grid, dim3(256), 0, st, a);
-  else if (big_co) hipLaunchKernelGGL((wg_kernel<T, 128, 64>), grid, dim3(256), 0, st, a);
-  else if (big_ci) hipLaunchKernelGGL((wg_kernel<T, 64, 128>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wg_kernel<T, 64, 64>), grid, dim3(256), 0, st, a);
+  static const bool no_rowstep = getenv("DG_WG_GENERIC") != nullptr;
+  const bool rs = !no_rowstep && a.Wo % 32 == 0;
+#define WG_LAUNCH(BCO, BCI)                                                                           \
+  do {                                                                                                \
+    if (rs) hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, true>), grid, dim3(256), 0, st, a);            \
+    else hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, false>), grid, dim3(256), 0, st, a);              \
+  } while (0)
+  if (big_co && big_ci) WG_LAUNCH(128, 128);
+  else if (big_co) WG_LAUNCH(128, 64);
+  else if (big_ci) WG_LAUNCH(64, 128);
+  else WG_LAUNCH(64, 64);
+#undef WG_LAUNCH
   return dg_check_launch();
 }
 

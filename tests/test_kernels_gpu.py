@@ -43,6 +43,9 @@ CONVS = [
     (1, 20, 12, 80, 48, 1, False),
     (3, 6, 10, 16, 128, 1, False),
     (1, 32, 32, 128, 16, 1, False),
+    (1, 64, 64, 64, 128, 2, False),     # Wo = 32: row-aligned K-steps in wgrad, halo tiles in dgrad
+    (1, 32, 32, 64, 256, 1, True),
+    (2, 32, 64, 128, 128, 1, False),
 ]
 
 
