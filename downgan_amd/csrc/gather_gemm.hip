@@ -667,11 +667,15 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
     const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;
     read_frags(fa1, fb1, cb, tap, wb, 1);
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
     mma_block(fa0, fb0);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (s + 1 < nsteps) read_frags(fa0, fb0, cb1, tap1, wb1, 0);
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
     mma_block(fa1, fb1);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if ((ABL != 2 && ABL != 4) && s + 2 < nsteps) store_w(rst, wb2);
     if ((ABL != 2 && ABL != 4) && cb + 1 < ncb && tap == (ntaps >= 2 ? ntaps - 2 : 0)) store_patch((cb + 1) & 1);
