@@ -25,7 +25,7 @@ class Epilogue(C.Structure):
 
 class ConvGeom(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("Cin", C.c_int), ("Cout", C.c_int), ("stride", C.c_int), ("pixel_shuffle", C.c_int),
+                ("Cin", C.c_int), ("Cout", C.c_int), ("stride", C.c_int), ("cin_real", C.c_int), ("pixel_shuffle", C.c_int),
                 ("ldx", C.c_int64), ("ldy", C.c_int64)]
 
 
@@ -44,7 +44,7 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
     "dg_conv3x3_fwd": [C.POINTER(ConvGeom), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_dgrad": [C.POINTER(ConvGeom), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
-    "dg_conv3x3_wgrad": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp],
+    "dg_conv3x3_wgrad": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp],
     "dg_gather_gemm": [C.POINTER(GGDesc), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_plan": [C.POINTER(ConvGeom), _i, C.POINTER(GGDesc)],
     "dg_colsum": [_i, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp],

@@ -20,6 +20,7 @@ struct WGArgs {
   int u_ps, cps_chunks;
   int Mpix, ppb;
   int nci_t;
+  float* db;       // IM2COL mode: bias gradient (column 18 of the im2col operand is the constant 1)
 };
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
@@ -30,10 +31,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4w_t;
 // ROWSTEP: Wo % KP == 0, so every K-step (KP consecutive output pixels) lies inside ONE output row: image / row
 // / first column are workgroup-uniform scalars and each thread's byte offsets are loop constants (raw buffer
 // loads, out-of-image taps get an out-of-range offset and read zeros).
-template <typename T, int BCO, int BCI, bool ROWSTEP>
+// IM2COL (layers with <= 2 real input channels, stride 1, e.g. the critic's first conv at 1024^2): instead of one
+// workgroup per tap, the input operand is the im2col row [9 taps x 2 channels | 1 | 0...] (64 columns) built on
+// the fly, so the adjoint (the only large tensor) is read ONCE for all taps and for the bias gradient.
+template <typename T, int BCO, int BCI, bool ROWSTEP, int KP, bool IM2COL = false>   // KP = pixels per K-step
 __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
   constexpr int EPC = DT<T>::EPC;
-  constexpr int KP = 32;                         // pixels per K-step
   constexpr int CPRU = BCO / EPC, CPRX = BCI / EPC;
   constexpr int NU = KP * CPRU / 256, NX = KP * CPRX / 256;   // 16-B chunks per thread
   static_assert(NU >= 1 && NX >= 1, "tile too small");
@@ -42,9 +45,9 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = blockIdx.x;
-  const int ci_t = bx % a.nci_t;
-  const int tap = (bx / a.nci_t) % 9;
-  const int co_t = bx / (a.nci_t * 9);
+  const int ci_t = IM2COL ? 0 : bx % a.nci_t;
+  const int tap = IM2COL ? 4 : (bx / a.nci_t) % 9;
+  const int co_t = IM2COL ? bx : bx / (a.nci_t * 9);
   const int co0 = co_t * BCO, ci0 = ci_t * BCI;
   const int dr = tap / 3 - 1, dc = tap % 3 - 1;
   const int pbeg = blockIdx.y * a.ppb;
@@ -57,6 +60,8 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
   int s_n = 0, s_ho = 0, s_wo = 0;
   unsigned uoffc[NU], xoffc[NX];
   int xrow[NX];
+  constexpr int TPC = EPC / 2;          // taps per 16-B chunk of the im2col row
+  unsigned imoff[IM2COL ? NX : 1][TPC];  // per-thread byte offsets of the chunk's taps (relative to pixel (ho-1, wo0-1))
   if constexpr (ROWSTEP) {
     s_wo = pbeg % a.Wo; const int t = pbeg / a.Wo; s_ho = t % a.Ho; s_n = t / a.Ho;
 #pragma unroll
@@ -76,6 +81,13 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
       const int ci = ci0 + col * EPC;
       xrow[i] = row;
       xoffc[i] = ci < a.Cin ? (unsigned)(((long long)row * a.stride * a.ldx + ci) * (int)sizeof(T)) : WG_OOB_OFF;
+      if constexpr (IM2COL) {
+#pragma unroll
+        for (int tt = 0; tt < TPC; ++tt) {
+          const int tp = col * TPC + tt;      // tap index of this pair of columns
+          imoff[i][tt] = tp < 9 ? (unsigned)((((long long)(tp / 3) * a.W + row + tp % 3) * a.ldx) * (int)sizeof(T)) : WG_OOB_OFF;
+        }
+      }
     }
   }
   auto gload_row = [&]() {
@@ -90,11 +102,39 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
     __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xb), 0, (int)WG_OOB_OFF, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NU; ++i) ru[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rU, uoffc[i], 0, 0));
+    if constexpr (IM2COL) {
+      // base = pixel (s_ho - 1, s_wo - 1) of image s_n; tap (r, s) of output pixel wo0+row is pixel (s_ho-1+r, s_wo-1+row+s)
+      const long long xb2 = ((long long)(s_n * a.H + s_ho - 1) * a.W + s_wo - 1) * a.ldx;
+      __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xb2), 0, (int)WG_OOB_OFF, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int wi = wi0 + xrow[i] * a.stride;
-      const unsigned vo = (row_ok && (unsigned)wi < (unsigned)a.W) ? xoffc[i] : WG_OOB_OFF;
-      rx[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, vo, 0, 0));
+      for (int i = 0; i < NX; ++i) {
+        const int col = (tid + 256 * i) % CPRX;
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int tt = 0; tt < TPC; ++tt) {
+          const int tp = col * TPC + tt;
+          const int hh = s_ho - 1 + tp / 3, ww = s_wo - 1 + xrow[i] + tp % 3;
+          const unsigned vo = (tp < 9 && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W) ? imoff[i][tt] : WG_OOB_OFF;
+          if constexpr (sizeof(T) == 2) {
+            unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rI, vo, 0, 0);
+            if (tp == 9) v = 0x3f80u;                          // bf16 (1.0, 0.0): the bias column
+            w[tt] = v;
+          } else {
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2w_t;
+            u32x2w_t v = __builtin_amdgcn_raw_buffer_load_b64(rI, vo, 0, 0);
+            if (tp == 9) { v[0] = 0x3f800000u; v[1] = 0u; }
+            w[2 * tt] = v[0]; w[2 * tt + 1] = v[1];
+          }
+        }
+        rx[i] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int wi = wi0 + xrow[i] * a.stride;
+        const unsigned vo = (row_ok && (unsigned)wi < (unsigned)a.W) ? xoffc[i] : WG_OOB_OFF;
+        rx[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, vo, 0, 0));
+      }
     }
     s_wo += KP;
     if (s_wo >= a.Wo) { s_wo = 0; if (++s_ho == a.Ho) { s_ho = 0; ++s_n; } }
@@ -245,9 +285,33 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int co = co0 + wco * (BCO / 2) + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (long long)co * ldw + tap * a.Cin + ci, acc[i][j][reg]);
+        if constexpr (IM2COL) {
+          if (co < a.Cout) {
+            if (ci < 18) atomicAdd(a.dw + (long long)co * ldw + (ci >> 1) * a.Cin + (ci & 1), acc[i][j][reg]);
+            else if (ci == 18 && a.db) atomicAdd(a.db + co, acc[i][j][reg]);
+          }
+        } else {
+          if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (long long)co * ldw + tap * a.Cin + ci, acc[i][j][reg]);
+        }
       }
     }
+}
+
+template <typename T>
+static int wg_launch_im2col(WGArgs& a, hipStream_t st) {
+  const bool big_co = a.Cout > 64;
+  const int bco = big_co ? 128 : 64;
+  const int nco_t = (a.Cout + bco - 1) / bco;
+  int splits = (2304 + nco_t - 1) / nco_t;
+  const int max_splits = (a.Mpix + 2047) / 2048;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.ppb = ((a.Mpix + splits - 1) / splits + 31) / 32 * 32;
+  splits = (a.Mpix + a.ppb - 1) / a.ppb;
+  dim3 grid(nco_t, splits);
+  if (big_co) hipLaunchKernelGGL((wg_kernel<T, 128, 64, true, 32, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wg_kernel<T, 64, 64, true, 32, true>), grid, dim3(256), 0, st, a);
+  return dg_check_launch();
 }
 
 template <typename T>
@@ -262,15 +326,19 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   const int max_splits = (a.Mpix + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  a.ppb = ((a.Mpix + splits - 1) / splits + 31) / 32 * 32;
+  a.ppb = ((a.Mpix + splits - 1) / splits + 63) / 64 * 64;
   splits = (a.Mpix + a.ppb - 1) / a.ppb;
   dim3 grid(ntiles, splits);
   static const bool no_rowstep = getenv("DG_WG_GENERIC") != nullptr;
   const bool rs = !no_rowstep && a.Wo % 32 == 0;
+  // 64-pixel K-steps halve the barrier count; they need Wo % 64 == 0 and 2 x 64 x (BCO+BCI) elements of LDS
+  static const bool no_kp64 = getenv("DG_WG_KP32") != nullptr;
+  const bool kp64 = rs && !no_kp64 && a.Wo % 64 == 0 && a.ppb % 64 == 0 && sizeof(T) == 2;
 #define WG_LAUNCH(BCO, BCI)                                                                           \
   do {                                                                                                \
-    if (rs) hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, true>), grid, dim3(256), 0, st, a);            \
-    else hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, false>), grid, dim3(256), 0, st, a);              \
+    if (kp64) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, true, 64>), grid, dim3(256), 0, st, a); } \
+    else if (rs) hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, true, 32>), grid, dim3(256), 0, st, a);   \
+    else hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, false, 32>), grid, dim3(256), 0, st, a);          \
   } while (0)
   if (big_co && big_ci) WG_LAUNCH(128, 128);
   else if (big_co) WG_LAUNCH(128, 64);
@@ -280,7 +348,10 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   return dg_check_launch();
 }
 
-extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void* dy, float* dw, void* stream) {
+extern "C" int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, int64_t rows_inner, int64_t ld, int C,
+                         float* db, void* stream);
+
+extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void* dy, float* dw, float* db, void* stream) {
   if (!g || !x || !dy || !dw) return DG_ERR_BAD_ARG;
   if (g->dtype != DG_F32 && g->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
   if (g->N <= 0 || g->H <= 0 || g->W <= 0 || (g->stride != 1 && g->stride != 2)) return DG_ERR_BAD_SHAPE;
@@ -297,6 +368,15 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
   const long long mp = (long long)g->N * a.Ho * a.Wo;
   if (mp >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
   a.Mpix = (int)mp;
+  a.db = db;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const bool no_im2col = getenv("DG_WG_NOIM2COL") != nullptr;
+  if (!no_im2col && g->cin_real > 0 && g->cin_real <= 2 && g->stride == 1 && !g->pixel_shuffle && a.Wo % 32 == 0)
+    return g->dtype == DG_F32 ? wg_launch_im2col<float>(a, st) : wg_launch_im2col<bf16_t>(a, st);
+  if (db) {   // bias gradient as a separate column-sum pass over the adjoint
+    if (g->pixel_shuffle) return DG_ERR_BAD_ARG;
+    int rc = dg_colsum(g->dtype, dy, mp, g->ldy, 1, g->ldy, g->Cout, db, stream);
+    if (rc) return rc;
+  }
   return g->dtype == DG_F32 ? wg_launch<float>(a, st) : wg_launch<bf16_t>(a, st);
 }

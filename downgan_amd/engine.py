@@ -145,7 +145,8 @@ class NativeCritic:
         self.convs = []
         h = fine_dim
         for l, st in enumerate(self.STRIDES):
-            self.convs.append(Conv(batch, h, h, self.c_pad[l], self.c_pad[l + 1], st, False))
+            self.convs.append(Conv(batch, h, h, self.c_pad[l], self.c_pad[l + 1], st, False,
+                                   cin_real=(nc if l == 0 and nc <= 2 else 0)))
             h //= st
         self.hf = h
         self.fc_k = h * h * self.c_pad[8]
@@ -246,10 +247,8 @@ class NativeCritic:
             cv = self.convs[l]
             name = f"features.{2 * l}.weight"
             xin = self.acts[l - 1] if l > 0 else x
-            if wgrad:
-                o.conv_wgrad(cv, xin, self.us[l], P.grad(name).reshape(-1))
-                if l == 0:
-                    o.colsum(self.us[0], P.grad("features.0.bias"))
+            if wgrad:   # features.0 also carries the only conv bias of the critic (critic.py:21-23)
+                o.conv_wgrad(cv, xin, self.us[l], P.grad(name).reshape(-1), db=P.grad("features.0.bias") if l == 0 else None)
             if l > 0:
                 o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask=self.acts[l - 1], mask_slope=C_SLOPE)
             elif dx is not None:
@@ -303,7 +302,7 @@ class NativeGenerator:
         self.cin_p, self.np_p = layout.pad16(channels), layout.pad16(n_predictands)
         self.nrb, self.nup = num_res_blocks, num_upsample
         F_, S, B = filters, coarse_side, batch
-        self.cv_conv1 = Conv(B, S, S, self.cin_p, F_)
+        self.cv_conv1 = Conv(B, S, S, self.cin_p, F_, cin_real=(channels if channels <= 2 else 0))
         self.cv_b = [Conv(B, S, S, k * F_, F_) for k in range(1, 6)]
         self.cv_conv2 = Conv(B, S, S, F_, F_)
         self.cv_up = [Conv(B, S << u, S << u, F_, 4 * F_, 1, True) for u in range(num_upsample)]
@@ -479,7 +478,7 @@ class NativeGenerator:
             gy, gyi = gyn, gyi ^ 1
         # conv1: d out1 = trunk-path gradient + skip gradient
         o.axpby(gy, gy, 1.0, d_trunk, 1.0)
-        o.conv_wgrad(self.cv_conv1, x, gy, GW("conv1")); o.colsum(gy, GB("conv1"))
+        o.conv_wgrad(self.cv_conv1, x, gy, GW("conv1"), db=GB("conv1"))
 
 
 # =============================================================================================== train step

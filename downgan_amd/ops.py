@@ -33,6 +33,7 @@ class Conv:
     Cout: int         # padded
     stride: int = 1
     pixel_shuffle: bool = False
+    cin_real: int = 0   # real (unpadded) input channels when that is <= 2, else 0
 
     @property
     def Ho(self):
@@ -99,7 +100,7 @@ class HipOps:
 
     def _geom(self, cv: Conv, ldx, ldy):
         return ConvGeom(dtype=self.dg, N=cv.N, H=cv.H, W=cv.W, Cin=cv.Cin, Cout=cv.Cout, stride=cv.stride,
-                        pixel_shuffle=int(cv.pixel_shuffle), ldx=ldx, ldy=ldy)
+                        cin_real=cv.cin_real, pixel_shuffle=int(cv.pixel_shuffle), ldx=ldx, ldy=ldy)
 
     def _epilogue(self, out, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None, mask_slope=1.0,
                   accumulate=False):
@@ -151,14 +152,16 @@ class HipOps:
         check(self._timed("conv_dgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_dgrad(
             C.byref(g), C.byref(e), _ptr(dy), _ptr(w_dgrad), _ptr(dx), self._stream())), "dg_conv3x3_dgrad")
 
-    def conv_wgrad(self, cv: Conv, x, dy, dw):
+    def conv_wgrad(self, cv: Conv, x, dy, dw, db=None):
+        """dw += weight gradient; db (optional, fp32 [Cout]) += bias gradient = column sums of dy."""
         self._act(x); self._act(dy)
         assert dw.dtype == torch.float32 and dw.numel() == cv.Cout * 9 * cv.Cin and dw.is_contiguous()
+        assert db is None or (db.dtype == torch.float32 and db.numel() >= cv.Cout and not cv.pixel_shuffle)
         assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin), (x.shape, cv)
         assert tuple(dy.shape) == self.out_shape(cv), (dy.shape, cv)
         g = self._geom(cv, pix_layout(x)[0], pix_layout(dy)[0])
         check(self._timed("conv_wgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad(
-            C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), self._stream())), "dg_conv3x3_wgrad")
+            C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), self._stream())), "dg_conv3x3_wgrad")
 
     def colsum(self, dy, db):
         """db[c] += sum over all pixels/rows of dy[..., c]; dy is NHWC (any dtype of {fp32, compute}) or 2-D."""

@@ -62,6 +62,9 @@ typedef struct dg_conv_geom {
   int N, H, W;          /* forward input: N images of H x W                                     */
   int Cin, Cout;        /* padded channel counts (multiples of 16; Cin may be a multiple of 8)   */
   int stride;           /* 1 or 2; output is Ho = H/stride, Wo = W/stride (H, W even if 2)       */
+  int cin_real;         /* number of REAL (non-padding) input channels, 0 = unknown/all. Layers   */
+                        /*    with <= 2 real channels (critic features.0, critic.py:21) take an    */
+                        /*    im2col path that reads the big tensor once for all 9 taps.           */
   int pixel_shuffle;    /* 1: the layer is followed by LeakyReLU + nn.PixelShuffle(2)            */
                         /*    (generator.py:69-75). Output channels are packed (2i+j)*Cout/4 + c */
                         /*    and the activation tensor is stored shuffled: [N,2Ho,2Wo,Cout/4].  */
@@ -104,7 +107,8 @@ int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, const void* d
 /* dw[Cout][9][Cin] (fp32) += sum_pixels dy (x) x   (atomic accumulate).  Replaces the autograd
  * weight-gradient of nn.Conv2d (wasserstein.py:52,80) and, with (x:=tangent, dy:=adjoint), the
  * double-backward term of the gradient penalty (wasserstein.py:100-117 under :52). */
-int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void* dy, float* dw, void* stream);
+int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void* dy, float* dw, float* db,
+                     void* stream);   /* db (optional): bias gradient += sum_pixels dy */
 
 /* db[c] (fp32) += sum over rows of dy[row, c]  (bias gradient of a conv or Linear).  Row r is at
  * element offset (r / rows_inner)*ld_outer + (r % rows_inner)*ld, so one sub-position of a

@@ -43,7 +43,7 @@ class EmuOps:
 
     def _plan(self, cv: Conv, kind, ldx, ldy):
         g = _lib.ConvGeom(dtype=self.dg, N=cv.N, H=cv.H, W=cv.W, Cin=cv.Cin, Cout=cv.Cout, stride=cv.stride,
-                          pixel_shuffle=int(cv.pixel_shuffle), ldx=ldx, ldy=ldy)
+                          cin_real=cv.cin_real, pixel_shuffle=int(cv.pixel_shuffle), ldx=ldx, ldy=ldy)
         d = (_lib.GGDesc * 4)()
         n = self.lib.dg_conv3x3_plan(C.byref(g), kind, d)
         assert n > 0, n
@@ -108,7 +108,9 @@ class EmuOps:
         for d in self._plan(cv, 1, pix_layout(dx)[0], pix_layout(dy)[0]):
             self._gather_gemm(d, dy, w_dgrad, dx, **ep)
 
-    def conv_wgrad(self, cv: Conv, x, dy, dw):
+    def conv_wgrad(self, cv: Conv, x, dy, dw, db=None):
+        if db is not None:
+            self.colsum(dy, db)
         u = dy.float()
         if cv.pixel_shuffle:
             cps = cv.Cout // 4

@@ -29,12 +29,12 @@ def test_library_exports_every_declared_symbol():
 def test_planner_rejects_bad_geometry():
     lib = _lib.lib()
     d = (_lib.GGDesc * 4)()
-    ok = _lib.ConvGeom(dtype=_lib.DG_BF16, N=1, H=8, W=8, Cin=16, Cout=16, stride=1, pixel_shuffle=0, ldx=16, ldy=16)
+    ok = _lib.ConvGeom(dtype=_lib.DG_BF16, N=1, H=8, W=8, Cin=16, Cout=16, stride=1, cin_real=0, pixel_shuffle=0, ldx=16, ldy=16)
     assert lib.dg_conv3x3_plan(C.byref(ok), 0, d) == 1
     assert lib.dg_conv3x3_plan(C.byref(ok), 1, d) == 1
     bad = [dict(stride=3), dict(Cin=12), dict(Cout=8), dict(dtype=7), dict(H=7, stride=2), dict(pixel_shuffle=1, Cout=32)]
     for kw in bad:
-        g = _lib.ConvGeom(dtype=_lib.DG_BF16, N=1, H=8, W=8, Cin=16, Cout=16, stride=1, pixel_shuffle=0, ldx=16, ldy=16)
+        g = _lib.ConvGeom(dtype=_lib.DG_BF16, N=1, H=8, W=8, Cin=16, Cout=16, stride=1, cin_real=0, pixel_shuffle=0, ldx=16, ldy=16)
         for k, v in kw.items():
             setattr(g, k, v)
         assert lib.dg_conv3x3_plan(C.byref(g), 0, d) < 0, kw
@@ -47,8 +47,8 @@ def test_planner_rejects_bad_geometry():
 
 def test_null_and_shape_errors_do_not_launch():
     lib = _lib.lib()
-    g = _lib.ConvGeom(dtype=_lib.DG_BF16, N=1, H=8, W=8, Cin=16, Cout=16, stride=1, pixel_shuffle=0, ldx=16, ldy=16)
+    g = _lib.ConvGeom(dtype=_lib.DG_BF16, N=1, H=8, W=8, Cin=16, Cout=16, stride=1, cin_real=0, pixel_shuffle=0, ldx=16, ldy=16)
     assert lib.dg_conv3x3_fwd(C.byref(g), None, None, None, None, None) == -3     # DG_ERR_BAD_ARG
-    assert lib.dg_conv3x3_wgrad(C.byref(g), None, None, None, None) == -3
+    assert lib.dg_conv3x3_wgrad(C.byref(g), None, None, None, None, None) == -3
     assert lib.dg_linear_fwd(_lib.DG_BF16, None, 0, None, 0, None, 0, 1, 16, 32, None) == -3
     assert lib.dg_adam(None, None, None, None, None, 16, 1e-3, 0.9, 0.99, 1e-8, 1, 1.0, None) == -3

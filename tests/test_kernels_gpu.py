@@ -250,3 +250,22 @@ def test_adam_and_layout():
             ref = torch.zeros(32 * 9 * 16, dtype=e.tdtype); e.repack(m_, ref, 32, 16, kind)
             dev = torch.zeros(32 * 9 * 16, dtype=e.tdtype).cuda(); h.repack(m_.cuda(), dev, 32, 16, kind)
             assert torch.equal(dev.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,co,cin_real", [(2, 32, 32, 128, 2), (1, 64, 32, 64, 2), (1, 16, 64, 128, 1), (1, 8, 12, 32, 2)])
+def test_conv_wgrad_small_cin_with_bias(dtype, N, H, W, co, cin_real):
+    """layers with <= 2 real input channels (critic features.0): im2col weight-gradient + fused bias gradient."""
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(11)
+    cv = Conv(N, H, W, 16, co, 1, False, cin_real=cin_real)
+    x = torch.zeros(N, H, W, 16, dtype=emu.tdtype)
+    x[..., :cin_real] = rnd((N, H, W, cin_real), emu.tdtype, g)
+    dy = rnd(emu.out_shape(cv), emu.tdtype, g)
+    dw_ref = torch.randn(co * 9 * 16, generator=g); db_ref = torch.randn(co, generator=g)
+    dw, db = dw_ref.clone().cuda(), db_ref.clone().cuda()
+    emu.conv_wgrad(cv, x, dy, dw_ref, db=db_ref)
+    hip.conv_wgrad(cv, x.cuda(), dy.cuda(), dw, db=db)
+    tol = 1e-5 if dtype == "f32" else 1e-4
+    assert (dw.cpu() - dw_ref).abs().max().item() <= tol * 8 * float(dw_ref.abs().max())
+    assert (db.cpu() - db_ref).abs().max().item() <= tol * 8 * float(db_ref.abs().max())
