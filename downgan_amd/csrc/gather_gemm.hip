@@ -736,6 +736,101 @@ static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
   return dg_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// im2col path for stride-1 FORWARD layers with <= 2 real input channels (critic features.0 on the
+// 1024^2 tiles, generator conv1 with 2 covariates).  K = 9 taps x 2 channels = 18, so
+// the layer is bound by writing its output to HBM, not by MFMA: the 18 (padded to 32) K values of every
+// pixel are gathered straight from the 2 real channels (4/8-byte loads) instead of walking 9 taps x 16
+// padded channels, the weight tile is built once per workgroup, and each workgroup streams several
+// 128-pixel tiles.
+template <typename T>
+__global__ __launch_bounds__(256) void gg_im2col_kernel(const GGArgs a, int tiles_per_block) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int KCH = 32 / EPC;         // 16-B chunks per 32-element K row
+  constexpr int TPC = EPC / 2;          // taps per chunk (2 channels per tap)
+  constexpr int NCH = 128 * KCH / 256;  // chunks per thread per tile
+  __shared__ uint4 sW[128 * KCH], sX[128 * KCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.y * 128;
+  const T* X = reinterpret_cast<const T*>(a.x);
+  const T* Wt = reinterpret_cast<const T*>(a.w);
+  auto swz = [](int row) { return KCH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+  auto load_pair = [](const T* p, unsigned* w2) {
+    if constexpr (sizeof(T) == 2) { w2[0] = *reinterpret_cast<const unsigned*>(p); }
+    else { const uint2 v = *reinterpret_cast<const uint2*>(p); w2[0] = v.x; w2[1] = v.y; }
+  };
+  // weight tile: row = output channel, K element k = tap*2 + ci
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int e = tid + 256 * i, row = e / KCH, col = e % KCH;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (c0 + row < a.Nout) {
+#pragma unroll
+      for (int tt = 0; tt < TPC; ++tt) {
+        const int tp = col * TPC + tt;
+        if (tp < 9) load_pair(Wt + ((long long)(c0 + row) * 9 + tp) * a.Cred, w + tt * (4 / TPC));
+      }
+    }
+    sW[row * KCH + (col ^ swz(row))] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  const int wp = wave & 1, wc = wave >> 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  for (int t = 0; t < tiles_per_block; ++t) {
+    const int p0 = (blockIdx.x * tiles_per_block + t) * 128;
+    if (p0 >= a.M) break;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = tid + 256 * i, row = e / KCH, col = e % KCH;
+      const int m = p0 + row;
+      unsigned w[4] = {0u, 0u, 0u, 0u};
+      if (m < a.M) {
+        const int gx = m % a.Wg, tq = m / a.Wg;
+        const int gy = tq % a.Hg, n = tq / a.Hg;
+#pragma unroll
+        for (int tt = 0; tt < TPC; ++tt) {
+          const int tp = col * TPC + tt;
+          const int sy = gy + tp / 3 - 1, sx = gx + tp % 3 - 1;
+          if (tp < 9 && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws)
+            load_pair(X + ((long long)(n * a.Hs + sy) * a.Ws + sx) * a.ldx, w + tt * (4 / TPC));
+        }
+      }
+      sX[row * KCH + (col ^ swz(row))] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KCH / 4; ++kk) {
+      const int ch = kk * 4 + g;
+      uint4 fa[4], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int row = wc * 64 + 16 * j + l15; fa[j] = sW[row * KCH + (ch ^ swz(row))]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int row = wp * 64 + 16 * i + l15; fb[i] = sX[row * KCH + (ch ^ swz(row))]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
+    }
+    gg_epilogue<T, 128, 128, 64, 64>(a, acc, p0, c0, wp, wc, l15, g);
+    __syncthreads();
+  }
+}
+
+template <typename T>
+static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
+  const int tiles = (a.M + 127) / 128;
+  int tpb = tiles / 2048;            // a few tiles per workgroup so the weight tile is built rarely
+  if (tpb < 1) tpb = 1;
+  if (tpb > 16) tpb = 16;
+  dim3 grid((tiles + tpb - 1) / tpb, (a.Nout + 127) / 128);
+  hipLaunchKernelGGL((gg_im2col_kernel<T>), grid, dim3(256), 0, st, a, tpb);
+  return dg_check_launch();
+}
+
 // ------------------------------------------------------------------------------------ host side
 static int gg_validate(const dg_gg_desc* d) {
   if (d->dtype != DG_F32 && d->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
@@ -791,8 +886,8 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   return gg_launch_t<T, 128, 16, 32, 16>(a, st);
 }
 
-extern "C" int dg_gather_gemm(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w,
-                              void* y, void* stream) {
+static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w, void* y, void* stream,
+                            bool im2col_small) {
   if (!d || !x || !w || !y) return DG_ERR_BAD_ARG;
   int rc = gg_validate(d);
   if (rc) return rc;
@@ -823,7 +918,14 @@ extern "C" int dg_gather_gemm(const dg_gg_desc* d, const dg_epilogue* ep, const 
     if ((a.r1 && a.ldr1 % 4) || (a.r2 && a.ldr2 % 4) || (a.mask && a.ldmask % 4)) return DG_ERR_BAD_SHAPE;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const bool no_im2col = getenv("DG_GG_NOIM2COL") != nullptr;
+  if (im2col_small && !no_im2col) return d->dtype == DG_F32 ? gg_launch_im2col<float>(a, st) : gg_launch_im2col<bf16_t>(a, st);
   return d->dtype == DG_F32 ? gg_launch<float>(a, d->N, st) : gg_launch<bf16_t>(a, d->N, st);
+}
+
+extern "C" int dg_gather_gemm(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w,
+                              void* y, void* stream) {
+  return gather_gemm_impl(d, ep, x, w, y, stream, false);
 }
 
 static int geom_validate(const dg_conv_geom* g) {
@@ -889,7 +991,8 @@ extern "C" int dg_conv3x3_fwd(const dg_conv_geom* g, const dg_epilogue* ep, cons
   dg_gg_desc d[4];
   int n = dg_conv3x3_plan(g, 0, d);
   if (n < 0) return n;
-  return dg_gather_gemm(&d[0], ep, x, w_fwd, y, stream);
+  const bool small = g->cin_real > 0 && g->cin_real <= 2 && g->stride == 1 && !g->pixel_shuffle;
+  return gather_gemm_impl(&d[0], ep, x, w_fwd, y, stream, small);
 }
 
 extern "C" int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, const void* dy, const void* w_dgrad,

@@ -269,3 +269,25 @@ def test_conv_wgrad_small_cin_with_bias(dtype, N, H, W, co, cin_real):
     tol = 1e-5 if dtype == "f32" else 1e-4
     assert (dw.cpu() - dw_ref).abs().max().item() <= tol * 8 * float(dw_ref.abs().max())
     assert (db.cpu() - db_ref).abs().max().item() <= tol * 8 * float(db_ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,co,cin_real", [(2, 32, 32, 128, 2), (1, 20, 12, 64, 2), (3, 16, 16, 16, 1), (1, 40, 24, 256, 2)])
+def test_conv_fwd_small_cin(dtype, N, H, W, co, cin_real):
+    """stride-1 forward with <= 2 real input channels: im2col kernel (bias+act, mask, residual epilogues)."""
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(12)
+    cv = Conv(N, H, W, 16, co, 1, False, cin_real=cin_real)
+    x = torch.zeros(N, H, W, 16, dtype=emu.tdtype)
+    x[..., :cin_real] = rnd((N, H, W, cin_real), emu.tdtype, g)
+    w = torch.zeros(co, 9, 16, dtype=emu.tdtype)
+    w[..., :cin_real] = rnd((co, 9, cin_real), emu.tdtype, g, 0.3)
+    w = w.reshape(-1)
+    b = torch.randn(co, generator=g)
+    msk = rnd(emu.out_shape(cv), emu.tdtype, g)
+    for ep in (dict(bias=b, act=0.2), dict(mask=msk, mask_slope=0.2), dict(bias=b, r1=msk, s1=0.5)):
+        y_ref = torch.zeros(emu.out_shape(cv), dtype=emu.tdtype)
+        y = torch.ones(emu.out_shape(cv), dtype=emu.tdtype).cuda()
+        emu.conv_fwd(cv, x, w, y_ref, **ep)
+        hip.conv_fwd(cv, x.cuda(), w.cuda(), y, **{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ep.items()})
+        close(y, y_ref, dtype, f"im2col fwd {list(ep)}")

@@ -36,7 +36,7 @@ def main():
     for name, N, H, ci, co, st, ps in LAYERS:
         if args.layers and not any(k in name for k in args.layers.split(',')):
             continue
-        cv = Conv(N, H, H, ci, co, st, ps)
+        cv = Conv(N, H, H, ci, co, st, ps, cin_real=(2 if ci == 16 and st == 1 else 0))
         x = torch.randn(N, H, H, ci, generator=g).to(o.tdtype).cuda()
         w = (torch.randn(co * 9 * ci, generator=g) * 0.05).to(o.tdtype).cuda()
         y = o.zeros(*o.out_shape(cv))
