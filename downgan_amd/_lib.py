@@ -47,6 +47,7 @@ _PROTOS = {
     "dg_conv3x3_wgrad": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp],
     "dg_gather_gemm": [C.POINTER(GGDesc), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_plan": [C.POINTER(ConvGeom), _i, C.POINTER(GGDesc)],
+    "dg_last_conv_kernels": [],
     "dg_colsum": [_i, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp],
     "dg_repack_conv_weights": [_i, _i, _vp, _vp, _i, _i, _vp],
     "dg_linear_fwd": [_i, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i64, _vp],

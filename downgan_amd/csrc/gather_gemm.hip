@@ -21,6 +21,10 @@
 
 #include <stdlib.h>
 
+// bit mask of the kernel variants the last dg_conv3x3_fwd / _dgrad call of this thread launched (bench.py tags its
+// live timings with it): 1 generic, 2 fast, 4 dma, 8 halo, 16 im2col
+static thread_local int g_last_kinds = 0;
+
 struct GGArgs {
   const void* x; const void* w; void* y;
   const float* bias; const void* r1; const void* r2; const void* mask;
@@ -715,6 +719,7 @@ static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
   a.nct = (unsigned)((a.Nout + 127) / 128);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  g_last_kinds |= 8;
   static const int abl = getenv("DG_ABL") ? atoi(getenv("DG_ABL")) : 0;
   if (abl) {   // timing-only diagnostic builds (wrong results by construction)
     static bool abl_set = false;
@@ -827,6 +832,7 @@ static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
   if (tpb < 1) tpb = 1;
   if (tpb > 16) tpb = 16;
   dim3 grid((tiles + tpb - 1) / tpb, (a.Nout + 127) / 128);
+  g_last_kinds |= 16;
   hipLaunchKernelGGL((gg_im2col_kernel<T>), grid, dim3(256), 0, st, a, tpb);
   return dg_check_launch();
 }
@@ -864,6 +870,7 @@ static int gg_launch_t(GGArgs& a, hipStream_t st) {
   static const bool force_generic = getenv("DG_GG_GENERIC") != nullptr;
   static const bool use_dma = getenv("DG_GG_DMA") != nullptr;
   const bool fast_ok = a.cch % 8 == 0 && (!a.src_ps || a.cps_src_chunks % 8 == 0) && !force_generic;
+  g_last_kinds |= (fast_ok && use_dma) ? 4 : (fast_ok ? 2 : 1);
   if (fast_ok && use_dma)
     hipLaunchKernelGGL((gg_dma_kernel<T, BP, BC, WP, WC>), dim3(a.nwg), dim3(256), 0, st, a);
   else if (fast_ok)
@@ -989,6 +996,7 @@ extern "C" int dg_conv3x3_plan(const dg_conv_geom* g, int kind, dg_gg_desc* out)
 extern "C" int dg_conv3x3_fwd(const dg_conv_geom* g, const dg_epilogue* ep, const void* x, const void* w_fwd,
                               void* y, void* stream) {
   dg_gg_desc d[4];
+  g_last_kinds = 0;
   int n = dg_conv3x3_plan(g, 0, d);
   if (n < 0) return n;
   const bool small = g->cin_real > 0 && g->cin_real <= 2 && g->stride == 1 && !g->pixel_shuffle;
@@ -999,6 +1007,7 @@ extern "C" int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, co
                                 void* dx, void* stream) {
   if (g && g->Cin % 16) return DG_ERR_BAD_SHAPE;  // dx channels are a GEMM N dimension
   dg_gg_desc d[4];
+  g_last_kinds = 0;
   int n = dg_conv3x3_plan(g, 1, d);
   if (n < 0) return n;
   for (int i = 0; i < n; ++i) {
@@ -1007,3 +1016,5 @@ extern "C" int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, co
   }
   return DG_OK;
 }
+
+extern "C" int dg_last_conv_kernels(void) { return g_last_kinds; }

@@ -86,6 +86,8 @@ class HipOps:
         s.record()
         rc = fn()
         e.record()
+        if tag in ("conv_fwd", "conv_dgrad"):
+            tag = f"{tag}:k{self.lib.dg_last_conv_kernels()}"   # which kernel variant(s) served the call
         self.prof.append((tag, flops, s, e))
         return rc
 

@@ -120,6 +120,10 @@ int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, i
 int dg_gather_gemm(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w, void* y,
                    void* stream);
 
+/* Which kernel variants the calling thread's last dg_conv3x3_fwd / _dgrad launched (bit mask: 1 generic
+ * gather-GEMM, 2 fast path, 4 LDS-DMA variant, 8 halo-patch kernel, 16 im2col small-Cin kernel). Diagnostic. */
+int dg_last_conv_kernels(void);
+
 /* Host-only planner (no GPU needed): lowers a layer to its gather-GEMM descriptor(s).
  * kind 0 = forward (1 desc), kind 1 = dgrad (1 desc for stride 1, 4 parity classes for stride 2).
  * Returns the number of descriptors written to out[0..3], or a negative dg_status. */
