@@ -837,6 +837,166 @@ static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
   return dg_check_launch();
 }
 
+// 8x16-pixel variant of the halo kernel: 4 waves, 78 KB of LDS -> TWO workgroups per CU whose barrier phases are
+// independent, so one workgroup's load / LDS-store / barrier phases overlap the other's MFMA blocks.
+template <typename T>
+__global__ __launch_bounds__(256) void gg_halo8_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TH = 8, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 180 patch rows
+  constexpr int BC = 128;
+  constexpr int NPL = (PROWS * 8 + 255) / 256;                           // 6 patch chunks per thread
+  constexpr int NWL = BC * 8 / 256;                                      // 4 weight chunks per thread
+  extern __shared__ __attribute__((aligned(16))) uint4 dsm[];
+  uint4* const s_patch = dsm;                   // [2][PROWS][8]
+  uint4* const s_w = dsm + 2 * PROWS * 8;       // [2][BC][8]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tile_c = tile % a.nct;
+  unsigned rest = tile / a.nct;
+  const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
+  const int ty0 = (rest % tiles_y) * TH;
+  const int img = rest / tiles_y;
+  const int c0 = tile_c * BC;
+  const int cc = tid & 7, r0 = tid >> 3;        // r0 in [0,32)
+
+  // patch rows owned by this thread: constant byte offsets relative to the workgroup base
+  const int sy_base = ty0 - 1 > 0 ? ty0 - 1 : 0;
+  unsigned poff[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int pr = r0 + 32 * i;
+    const int py = pr / PW, px = pr - py * PW;
+    const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+    const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+    poff[i] = ok ? (unsigned)(((long long)(sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
+  }
+  unsigned woff[NWL];
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    const int row = r0 + 32 * i;
+    woff[i] = (c0 + row < a.Nout) ? (unsigned)((long long)row * a.ldw * ES) + cc * 16 : DG_OOB_OFF;
+  }
+  const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
+  const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
+
+  u32x4_t rp[NPL], rw[NWL];
+  auto load_patch = [&](int cb) {
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * 8 * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, poff[i], 0, 0);
+  };
+  auto store_patch = [&](int buf) {
+    uint4* s = s_patch + buf * PROWS * 8;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0 + 32 * i;
+      if (pr < PROWS) s[pr * 8 + (cc ^ ((pr >> 1) & 7))] = __builtin_bit_cast(uint4, rp[i]);
+    }
+  };
+  auto load_w = [&](int cb, int tap) {
+    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
+    const long long wo = (long long)(code >> 4) * a.Cred + cb * 8 * EPC;
+    __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + wo * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rwd, woff[i], 0, 0);
+  };
+  auto store_w = [&](int buf) {
+    uint4* s = s_w + buf * BC * 8;
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int row = r0 + 32 * i;
+      s[row * 8 + (cc ^ ((row >> 1) & 7))] = __builtin_bit_cast(uint4, rw[i]);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int wp = wave & 1, wc = wave >> 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ncb = a.cch >> 3, ntaps = a.ntaps;
+  const int nsteps = ncb * ntaps;
+
+  load_patch(0);
+  load_w(0, 0);
+  store_patch(0);
+  store_w(0);
+  __syncthreads();
+
+  int cb = 0, tap = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    int ntap = tap + 1, ncbn = cb;
+    if (ntap == ntaps) { ntap = 0; ncbn = cb + 1; }
+    if (more) load_w(ncbn, ntap);
+    const bool next_cb = tap == 0 && cb + 1 < ncb;
+    if (next_cb) load_patch(cb + 1);
+
+    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
+    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
+    const uint4* sp = s_patch + (cb & 1) * PROWS * 8;
+    const uint4* sw = s_w + (s & 1) * BC * 8;
+    const int prow0 = (wp * 4 + 1 + dy) * PW + 1 + dx + l15;   // patch row of this lane's pixel in tile row wp*4
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = kk * 4 + g;
+      uint4 fa[4], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wc * 64 + 16 * j + l15;
+        fa[j] = sw[row * 8 + (ch ^ ((row >> 1) & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pr = prow0 + i * PW;
+        fb[i] = sp[pr * 8 + (ch ^ ((pr >> 1) & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
+    }
+    if (more) store_w((s + 1) & 1);
+    if (tap == ntaps - 1 && cb + 1 < ncb) store_patch((cb + 1) & 1);
+    __syncthreads();
+    tap = ntap; cb = ncbn;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gy = ty0 + wp * 4 + i, gx = tx0 + l15;
+    if (gy >= a.Hg || gx >= a.Wg) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co0 = c0 + wc * 64 + 16 * j + 4 * g;
+      if (co0 >= a.Nout) continue;
+      gg_store_frag<T>(a, acc[j][i], img, gy, gx, co0);
+    }
+  }
+}
+
+template <typename T>
+static int gg_launch_halo8(GGArgs& a, int N, hipStream_t st) {
+  constexpr int LDS_BYTES = (2 * 180 + 2 * 128) * 8 * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo8_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return DG_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 7) / 8;
+  a.nct = (unsigned)((a.Nout + 127) / 128);
+  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  g_last_kinds |= 32;
+  hipLaunchKernelGGL((gg_halo8_kernel<T>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, tiles_x, tiles_y);
+  return dg_check_launch();
+}
+
 // ------------------------------------------------------------------------------------ host side
 static int gg_validate(const dg_gg_desc* d) {
   if (d->dtype != DG_F32 && d->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
@@ -886,7 +1046,10 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   // the patch is sized for tap shifts in [-1, 1] around a unit-stride grid (stride-1 forward, all data gradients)
   if (!no_halo && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 &&
       a.Hs == a.Hg && a.Ws == a.Wg)
-    return gg_launch_halo<T>(a, N, st);
+  {
+    static const bool use_halo8 = getenv("DG_GG_HALO8") != nullptr;
+    return use_halo8 ? gg_launch_halo8<T>(a, N, st) : gg_launch_halo<T>(a, N, st);
+  }
   if (a.Nout > 64) return gg_launch_t<T, 128, 128, 64, 64>(a, st);
   if (a.Nout > 32) return gg_launch_t<T, 128, 64, 64, 32>(a, st);
   if (a.Nout > 16) return gg_launch_t<T, 128, 32, 32, 32>(a, st);
