@@ -22,7 +22,7 @@
 #include <stdlib.h>
 
 // bit mask of the kernel variants the last dg_conv3x3_fwd / _dgrad call of this thread launched (bench.py tags its
-// live timings with it): 1 generic, 2 fast, 4 dma, 8 halo, 16 im2col
+// live timings with it): 1 generic, 2 fast, 8 halo, 16 im2col
 static thread_local int g_last_kinds = 0;
 
 struct GGArgs {
@@ -393,132 +393,6 @@ __global__ __launch_bounds__(256) void gg_fast_kernel(const GGArgs a) {
   gg_epilogue<T, BP, BC, WP, WC>(a, acc, p0, c0, wp, wc, l15, g);
 }
 
-__device__ uint4 dg_zero_page[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-
-template <typename T, int BP, int BC, int WP, int WC>
-__global__ __launch_bounds__(256) void gg_dma_kernel(const GGArgs a) {
-  constexpr int EPC = DT<T>::EPC;
-  constexpr int ES = (int)sizeof(T);
-  constexpr int NPW = BP / WP;
-  constexpr int FP = WP / 16, FC = WC / 16;
-  constexpr int PR = BP / 32;
-  constexpr int CR = (BC + 31) / 32;
-  constexpr int ROWS = BP + BC;
-  static_assert((BP / WP) * (BC / WC) == 4, "4 waves per workgroup");
-  __shared__ uint4 smem[2 * ROWS * 8];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
-  const int tile_c = tile % a.nct, tile_p = tile / a.nct;
-  const int p0 = tile_p * BP, c0 = tile_c * BC;
-  const int cc = tid & 7, r0 = tid >> 3;
-  const int Wsrc = a.src_ps ? 2 * a.Ws : a.Ws, Hsrc = a.src_ps ? 2 * a.Hs : a.Hs, psm = a.src_ps ? 2 : 1;
-
-  // LDS-DMA staging: every lane fetches one 16-B chunk straight into LDS (global_load_lds_dwordx4).  The
-  // LDS image is lane-linear per wave-instruction (row = 32*i + tid/8, position = tid%8), so the XOR swizzle
-  // is applied on the SOURCE side: the lane at position cpos fetches logical chunk cpos ^ ((row>>1)&7).
-  // Padded / out-of-range rows fetch from a 64-B page of zeros.
-  const char* rowptr[PR];
-  unsigned vmask[PR];
-  const char* const zpage = reinterpret_cast<const char*>(dg_zero_page);
-#pragma unroll
-  for (int i = 0; i < PR; ++i) {
-    const int row = r0 + 32 * i, m = p0 + row;
-    rowptr[i] = zpage; vmask[i] = 0;
-    if (m < a.M) {
-      const int gx = m % a.Wg, t = m / a.Wg;
-      const int gy = t % a.Hg, im = t / a.Hg;
-      const int sy0 = gy * a.sy_mul, sx0 = gx * a.sx_mul;
-      const long long p = ((long long)im * Hsrc + (long long)sy0 * psm) * Wsrc + (long long)sx0 * psm;
-      rowptr[i] = reinterpret_cast<const char*>(a.x) + p * a.ldx * ES + ((cc ^ ((row >> 1) & 7)) * 16);
-      for (int t2 = 0; t2 < a.ntaps; ++t2) {
-        const unsigned code = t2 < 8 ? (unsigned)((a.tap_lo >> (8 * t2)) & 0xffull) : (a.tap_hi & 0xffu);
-        const int sy = sy0 + (int)(code & 3u) - 1, sx = sx0 + (int)((code >> 2) & 3u) - 1;
-        if ((unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws) vmask[i] |= 1u << t2;
-      }
-    }
-  }
-  const char* wptr[CR];
-#pragma unroll
-  for (int i = 0; i < CR; ++i) {
-    const int row = r0 + 32 * i;
-    wptr[i] = (row < BC && c0 + row < a.Nout)
-                  ? reinterpret_cast<const char*>(a.w) + (long long)(c0 + row) * a.ldw * ES + ((cc ^ ((row >> 1) & 7)) * 16)
-                  : nullptr;
-  }
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-
-  int tap = 0, cbase = 0;          // workgroup-uniform K position (SGPRs)
-  auto gload = [&](int buf) {
-    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
-    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1, ws = (int)(code >> 4);
-    long long xo;
-    if (!a.src_ps) xo = ((long long)dy * a.Ws + dx) * a.ldx + cbase * EPC;
-    else {
-      const int q = cbase / a.cps_src_chunks, cq = cbase - q * a.cps_src_chunks;
-      xo = ((long long)(2 * dy + (q >> 1)) * Wsrc + (2 * dx + (q & 1))) * a.ldx + cq * EPC;
-    }
-    const long long wo = (long long)ws * a.Cred + cbase * EPC;
-    uint4* s = smem + buf * ROWS * 8;
-#pragma unroll
-    for (int i = 0; i < PR; ++i) {
-      const char* src = ((vmask[i] >> tap) & 1u) ? rowptr[i] + xo * ES : zpage;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s + 256 * i + 64 * wave), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < CR; ++i) {
-      if (32 * i + 8 * wave < BC) {   // wave-uniform: this wave's 8 rows exist in the BC-row weight tile
-        const char* src = wptr[i] ? wptr[i] + wo * ES : zpage;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s + BP * 8 + 256 * i + 64 * wave), 16, 0, 0);
-      }
-    }
-    cbase += 8;
-    if (cbase >= a.cch) { cbase = 0; ++tap; }
-  };
-
-  f32x4_t acc[FC][FP];
-#pragma unroll
-  for (int j = 0; j < FC; ++j)
-#pragma unroll
-    for (int i = 0; i < FP; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int wp = wave % NPW, wc = wave / NPW;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int nk = a.kchunks >> 3;
-
-  gload(0);
-  __syncthreads();
-  int cur = 0;
-  for (int ks = 0; ks < nk; ++ks) {
-    const bool more = ks + 1 < nk;
-    if (more) gload(cur ^ 1);
-    const uint4* s = smem + cur * ROWS * 8;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ch = kk * 4 + g;
-      uint4 fa[FC], fb[FP];
-#pragma unroll
-      for (int j = 0; j < FC; ++j) {
-        const int row = wc * WC + 16 * j + l15;
-        fa[j] = s[(BP + row) * 8 + (ch ^ ((row >> 1) & 7))];
-      }
-#pragma unroll
-      for (int i = 0; i < FP; ++i) {
-        const int row = wp * WP + 16 * i + l15;
-        fb[i] = s[row * 8 + (ch ^ ((row >> 1) & 7))];
-      }
-#pragma unroll
-      for (int j = 0; j < FC; ++j)
-#pragma unroll
-        for (int i = 0; i < FP; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-  gg_epilogue<T, BP, BC, WP, WC>(a, acc, p0, c0, wp, wc, l15, g);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Halo path (unit-stride gathers: stride-1 forward, every data gradient).  One workgroup = a 16x16 tile of
 // the GEMM-row grid of ONE image x 128 output channels, 8 waves (wave = 4 tile rows x 64 channels).
@@ -528,7 +402,7 @@ __global__ __launch_bounds__(256) void gg_dma_kernel(const GGArgs a) {
 // weights stream per tap-step.  Per 9 tap-steps: 41 KB patch + 144 KB weights for 2x the flops of the
 // per-tap kernel's 288 KB -> 3.1x fewer bytes through the vector-memory path per flop, and the patch of
 // the NEXT channel block has a whole 9-step window to arrive.
-template <typename T, int ABL = 0>   // ABL: timing-only ablations (1 = no MFMA, 2 = no global loads/LDS stores, 3 = no fragment reads)
+template <typename T>
 __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_x, int tiles_y) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int ES = (int)sizeof(T);
@@ -623,13 +497,11 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = wc * 64 + 16 * j + l15;
-      if ((ABL == 3 || ABL == 4)) fa[j] = make_uint4(row, ch, tapx, 1); else
       fa[j] = sw[row * 8 + (ch ^ ((row >> 1) & 7))];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pr = prow0 + i * PW;
-      if ((ABL == 3 || ABL == 4)) fb[i] = make_uint4(pr, ch, tapx, 2); else
       fb[i] = sp[pr * 8 + (ch ^ ((pr >> 1) & 7))];
     }
   };
@@ -638,8 +510,7 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (ABL == 1) { asm volatile("" :: "v"(fa[j].x), "v"(fb[i].x)); }
-        else Mma<T>::run(fa[j], fb[i], acc[j][i]);
+        Mma<T>::run(fa[j], fb[i], acc[j][i]);
       }
   };
 
@@ -666,8 +537,8 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
   read_frags(fa0, fb0, 0, 0, 0, 0);
   // `rst` holds weights of step s+2 (fetched during step s-1); `rld` receives step s+3.
   auto step = [&](int s, u32x4_t (&rst)[2], u32x4_t (&rld)[2]) {
-    if ((ABL != 2 && ABL != 4) && s + 3 < nsteps) load_w(rld, cbn, tapn);
-    if ((ABL != 2 && ABL != 4) && tap == 0 && cb + 1 < ncb) load_patch(cb + 1);
+    if (s + 3 < nsteps) load_w(rld, cbn, tapn);
+    if (tap == 0 && cb + 1 < ncb) load_patch(cb + 1);
     const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;
     read_frags(fa1, fb1, cb, tap, wb, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -681,8 +552,8 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
     mma_block(fa1, fb1);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if ((ABL != 2 && ABL != 4) && s + 2 < nsteps) store_w(rst, wb2);
-    if ((ABL != 2 && ABL != 4) && cb + 1 < ncb && tap == (ntaps >= 2 ? ntaps - 2 : 0)) store_patch((cb + 1) & 1);
+    if (s + 2 < nsteps) store_w(rst, wb2);
+    if (cb + 1 < ncb && tap == (ntaps >= 2 ? ntaps - 2 : 0)) store_patch((cb + 1) & 1);
     __syncthreads();
     wb = wb1;
     advance(cb, tap);
@@ -712,7 +583,7 @@ static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
   constexpr int LDS_BYTES = (2 * 324 + 3 * 128) * 8 * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return DG_ERR_LAUNCH;
     attr_set = true;
   }
@@ -720,24 +591,7 @@ static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
   a.nct = (unsigned)((a.Nout + 127) / 128);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
   g_last_kinds |= 8;
-  static const int abl = getenv("DG_ABL") ? atoi(getenv("DG_ABL")) : 0;
-  if (abl) {   // timing-only diagnostic builds (wrong results by construction)
-    static bool abl_set = false;
-    if (!abl_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      abl_set = true;
-    }
-    if (abl == 4) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      hipLaunchKernelGGL((gg_halo_kernel<T, 4>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
-    } else if (abl == 1) hipLaunchKernelGGL((gg_halo_kernel<T, 1>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
-    else if (abl == 2) hipLaunchKernelGGL((gg_halo_kernel<T, 2>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
-    else hipLaunchKernelGGL((gg_halo_kernel<T, 3>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
-    return dg_check_launch();
-  }
-  hipLaunchKernelGGL((gg_halo_kernel<T, 0>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL((gg_halo_kernel<T>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
   return dg_check_launch();
 }
 
@@ -837,166 +691,6 @@ static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
   return dg_check_launch();
 }
 
-// 8x16-pixel variant of the halo kernel: 4 waves, 78 KB of LDS -> TWO workgroups per CU whose barrier phases are
-// independent, so one workgroup's load / LDS-store / barrier phases overlap the other's MFMA blocks.
-template <typename T>
-__global__ __launch_bounds__(256) void gg_halo8_kernel(const GGArgs a, int tiles_x, int tiles_y) {
-  constexpr int EPC = DT<T>::EPC;
-  constexpr int ES = (int)sizeof(T);
-  constexpr int TH = 8, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 180 patch rows
-  constexpr int BC = 128;
-  constexpr int NPL = (PROWS * 8 + 255) / 256;                           // 6 patch chunks per thread
-  constexpr int NWL = BC * 8 / 256;                                      // 4 weight chunks per thread
-  extern __shared__ __attribute__((aligned(16))) uint4 dsm[];
-  uint4* const s_patch = dsm;                   // [2][PROWS][8]
-  uint4* const s_w = dsm + 2 * PROWS * 8;       // [2][BC][8]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
-  const int tile_c = tile % a.nct;
-  unsigned rest = tile / a.nct;
-  const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
-  const int ty0 = (rest % tiles_y) * TH;
-  const int img = rest / tiles_y;
-  const int c0 = tile_c * BC;
-  const int cc = tid & 7, r0 = tid >> 3;        // r0 in [0,32)
-
-  // patch rows owned by this thread: constant byte offsets relative to the workgroup base
-  const int sy_base = ty0 - 1 > 0 ? ty0 - 1 : 0;
-  unsigned poff[NPL];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int pr = r0 + 32 * i;
-    const int py = pr / PW, px = pr - py * PW;
-    const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
-    const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-    poff[i] = ok ? (unsigned)(((long long)(sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
-  }
-  unsigned woff[NWL];
-#pragma unroll
-  for (int i = 0; i < NWL; ++i) {
-    const int row = r0 + 32 * i;
-    woff[i] = (c0 + row < a.Nout) ? (unsigned)((long long)row * a.ldw * ES) + cc * 16 : DG_OOB_OFF;
-  }
-  const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
-  const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
-
-  u32x4_t rp[NPL], rw[NWL];
-  auto load_patch = [&](int cb) {
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * 8 * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, poff[i], 0, 0);
-  };
-  auto store_patch = [&](int buf) {
-    uint4* s = s_patch + buf * PROWS * 8;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const int pr = r0 + 32 * i;
-      if (pr < PROWS) s[pr * 8 + (cc ^ ((pr >> 1) & 7))] = __builtin_bit_cast(uint4, rp[i]);
-    }
-  };
-  auto load_w = [&](int cb, int tap) {
-    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
-    const long long wo = (long long)(code >> 4) * a.Cred + cb * 8 * EPC;
-    __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + wo * ES), 0, (int)DG_OOB_OFF, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rwd, woff[i], 0, 0);
-  };
-  auto store_w = [&](int buf) {
-    uint4* s = s_w + buf * BC * 8;
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) {
-      const int row = r0 + 32 * i;
-      s[row * 8 + (cc ^ ((row >> 1) & 7))] = __builtin_bit_cast(uint4, rw[i]);
-    }
-  };
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int wp = wave & 1, wc = wave >> 1;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int ncb = a.cch >> 3, ntaps = a.ntaps;
-  const int nsteps = ncb * ntaps;
-
-  load_patch(0);
-  load_w(0, 0);
-  store_patch(0);
-  store_w(0);
-  __syncthreads();
-
-  int cb = 0, tap = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    const bool more = s + 1 < nsteps;
-    int ntap = tap + 1, ncbn = cb;
-    if (ntap == ntaps) { ntap = 0; ncbn = cb + 1; }
-    if (more) load_w(ncbn, ntap);
-    const bool next_cb = tap == 0 && cb + 1 < ncb;
-    if (next_cb) load_patch(cb + 1);
-
-    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
-    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
-    const uint4* sp = s_patch + (cb & 1) * PROWS * 8;
-    const uint4* sw = s_w + (s & 1) * BC * 8;
-    const int prow0 = (wp * 4 + 1 + dy) * PW + 1 + dx + l15;   // patch row of this lane's pixel in tile row wp*4
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ch = kk * 4 + g;
-      uint4 fa[4], fb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wc * 64 + 16 * j + l15;
-        fa[j] = sw[row * 8 + (ch ^ ((row >> 1) & 7))];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pr = prow0 + i * PW;
-        fb[i] = sp[pr * 8 + (ch ^ ((pr >> 1) & 7))];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
-    }
-    if (more) store_w((s + 1) & 1);
-    if (tap == ntaps - 1 && cb + 1 < ncb) store_patch((cb + 1) & 1);
-    __syncthreads();
-    tap = ntap; cb = ncbn;
-  }
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gy = ty0 + wp * 4 + i, gx = tx0 + l15;
-    if (gy >= a.Hg || gx >= a.Wg) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int co0 = c0 + wc * 64 + 16 * j + 4 * g;
-      if (co0 >= a.Nout) continue;
-      gg_store_frag<T>(a, acc[j][i], img, gy, gx, co0);
-    }
-  }
-}
-
-template <typename T>
-static int gg_launch_halo8(GGArgs& a, int N, hipStream_t st) {
-  constexpr int LDS_BYTES = (2 * 180 + 2 * 128) * 8 * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo8_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return DG_ERR_LAUNCH;
-    attr_set = true;
-  }
-  const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 7) / 8;
-  a.nct = (unsigned)((a.Nout + 127) / 128);
-  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
-  g_last_kinds |= 32;
-  hipLaunchKernelGGL((gg_halo8_kernel<T>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, tiles_x, tiles_y);
-  return dg_check_launch();
-}
-
 // ------------------------------------------------------------------------------------ host side
 static int gg_validate(const dg_gg_desc* d) {
   if (d->dtype != DG_F32 && d->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
@@ -1028,12 +722,9 @@ static int gg_launch_t(GGArgs& a, hipStream_t st) {
   const unsigned npt = (unsigned)((a.M + BP - 1) / BP);
   a.nwg = a.nct * npt;
   static const bool force_generic = getenv("DG_GG_GENERIC") != nullptr;
-  static const bool use_dma = getenv("DG_GG_DMA") != nullptr;
   const bool fast_ok = a.cch % 8 == 0 && (!a.src_ps || a.cps_src_chunks % 8 == 0) && !force_generic;
-  g_last_kinds |= (fast_ok && use_dma) ? 4 : (fast_ok ? 2 : 1);
-  if (fast_ok && use_dma)
-    hipLaunchKernelGGL((gg_dma_kernel<T, BP, BC, WP, WC>), dim3(a.nwg), dim3(256), 0, st, a);
-  else if (fast_ok)
+  g_last_kinds |= fast_ok ? 2 : 1;
+  if (fast_ok)
     hipLaunchKernelGGL((gg_fast_kernel<T, BP, BC, WP, WC>), dim3(a.nwg), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((gg_kernel<T, BP, BC, WP, WC>), dim3(a.nwg), dim3(256), 0, st, a);
@@ -1046,10 +737,7 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   // the patch is sized for tap shifts in [-1, 1] around a unit-stride grid (stride-1 forward, all data gradients)
   if (!no_halo && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 &&
       a.Hs == a.Hg && a.Ws == a.Wg)
-  {
-    static const bool use_halo8 = getenv("DG_GG_HALO8") != nullptr;
-    return use_halo8 ? gg_launch_halo8<T>(a, N, st) : gg_launch_halo<T>(a, N, st);
-  }
+    return gg_launch_halo<T>(a, N, st);
   if (a.Nout > 64) return gg_launch_t<T, 128, 128, 64, 64>(a, st);
   if (a.Nout > 32) return gg_launch_t<T, 128, 64, 64, 32>(a, st);
   if (a.Nout > 16) return gg_launch_t<T, 128, 32, 32, 32>(a, st);

@@ -38,7 +38,6 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const T* __restrict__ x, l
   for (int j = 0; j < NO; ++j)
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
   for (long long k = k0 + g * EPC; k < k1; k += 4 * EPC) {
     uint4 fb[NB], fa[NO];
 #pragma unroll

@@ -297,192 +297,6 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Row-of-taps weight gradient (stride 1 or 2, Wo % 32 == 0).  The per-tap kernel above re-reads the adjoint
-// tile for each of the 9 taps and the input tile for each tap as well: 8-10x the algorithmic HBM bytes
-// (measured with FETCH_SIZE), which makes the big-image layers bandwidth-bound.  Here one workgroup owns a
-// kernel ROW r (taps s = 0,1,2): per K-step (32 consecutive output pixels of one output row) it stages the
-// adjoint tile once and ONE input-row segment of (32-1)*stride+3 pixels, and the three taps read their input
-// fragments from that segment at row offsets k*stride+s.  3 accumulator sets (192 VGPRs), 24 MFMAs per K-step.
-template <typename T, int BCO, int BCI>
-__global__ __launch_bounds__(256, 2) void wg3_kernel(const WGArgs a) {
-  constexpr int EPC = DT<T>::EPC;
-  constexpr int KP = 32;
-  constexpr int PXMAX = (KP - 1) * 2 + 3;        // input pixels per segment at stride 2
-  constexpr int CPRU = BCO / EPC, CPRX = BCI / EPC;
-  constexpr int NU = KP * CPRU / 256;
-  constexpr int NX = (PXMAX * CPRX + 255) / 256;
-  constexpr int FA = BCO / 64, FB = BCI / 64;
-  __shared__ __attribute__((aligned(16))) T smem[2 * (KP * BCO + PXMAX * BCI)];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bx = blockIdx.x;
-  const int ci_t = bx % a.nci_t;
-  const int r = (bx / a.nci_t) % 3;
-  const int co_t = bx / (a.nci_t * 3);
-  const int co0 = co_t * BCO, ci0 = ci_t * BCI;
-  const int st = a.stride;
-  const int PX = (KP - 1) * st + 3;
-  const int pbeg = blockIdx.y * a.ppb;
-  const int pend = min(a.Mpix, pbeg + a.ppb);
-  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ U = reinterpret_cast<const T*>(a.u);
-
-  int s_wo = pbeg % a.Wo, s_ho, s_n;
-  { const int t = pbeg / a.Wo; s_ho = t % a.Ho; s_n = t / a.Ho; }
-  unsigned uoffc[NU], xoffc[NX];
-  int xprow[NX];
-#pragma unroll
-  for (int i = 0; i < NU; ++i) {
-    const int e = tid + 256 * i, row = e / CPRU, col = e % CPRU;
-    const int co = co0 + col * EPC;
-    if (co >= a.Cout) { uoffc[i] = WG_OOB_OFF; continue; }
-    if (!a.u_ps) uoffc[i] = (unsigned)(((long long)row * a.ldu + co) * (int)sizeof(T));
-    else {
-      const int cchunk = co / EPC, q = cchunk / a.cps_chunks, c = cchunk - q * a.cps_chunks;
-      uoffc[i] = (unsigned)((((long long)(q >> 1) * (2 * a.Wo) + 2 * row + (q & 1)) * a.ldu + c * EPC) * (int)sizeof(T));
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int e = tid + 256 * i, prow = e / CPRX, col = e % CPRX;
-    const int ci = ci0 + col * EPC;
-    xprow[i] = prow;
-    xoffc[i] = (prow < PX && ci < a.Cin) ? (unsigned)(((long long)prow * a.ldx + ci) * (int)sizeof(T)) : WG_OOB_OFF;
-  }
-  uint4 ru[NU], rx[NX];
-  auto gload = [&]() {
-    const long long ub = !a.u_ps ? ((long long)(s_n * a.Ho + s_ho) * a.Wo + s_wo) * a.ldu
-                                 : ((long long)(s_n * 2 * a.Ho + 2 * s_ho) * (2 * a.Wo) + 2 * s_wo) * a.ldu;
-    const int hi = s_ho * st + r - 1;
-    const bool row_ok = (unsigned)hi < (unsigned)a.H;
-    const int wi0 = s_wo * st - 1;                     // input column of segment row 0
-    const long long xb = ((long long)(s_n * a.H + hi) * a.W + wi0) * a.ldx;
-    __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)(U + ub), 0, (int)WG_OOB_OFF, 0x00020000);
-    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xb), 0, (int)WG_OOB_OFF, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NU; ++i) ru[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rU, uoffc[i], 0, 0));
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int wi = wi0 + xprow[i];
-      const unsigned vo = (row_ok && (unsigned)wi < (unsigned)a.W) ? xoffc[i] : WG_OOB_OFF;
-      rx[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rX, vo, 0, 0));
-    }
-    s_wo += KP;
-    if (s_wo >= a.Wo) { s_wo = 0; if (++s_ho == a.Ho) { s_ho = 0; ++s_n; } }
-  };
-  auto lstore = [&](int buf) {
-    T* su = smem + buf * (KP * BCO + PXMAX * BCI);
-    T* sx = su + KP * BCO;
-#pragma unroll
-    for (int i = 0; i < NU; ++i) {
-      const int e = tid + 256 * i, row = e / CPRU, col = e % CPRU;
-      *reinterpret_cast<uint4*>(su + row * BCO + col * EPC) = ru[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int e = tid + 256 * i, prow = e / CPRX, col = e % CPRX;
-      if (prow < PXMAX) *reinterpret_cast<uint4*>(sx + prow * BCI + col * EPC) = rx[i];
-    }
-  };
-
-  f32x16_t acc[3][FA][FB];
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int i = 0; i < FA; ++i)
-#pragma unroll
-      for (int j = 0; j < FB; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[s][i][j][e] = 0.f;
-
-  const int wco = wave & 1, wci = wave >> 1;
-  const int r32 = lane & 31, h = lane >> 5;
-  const int nsteps = (pend - pbeg) / KP;
-  if (nsteps <= 0) return;
-
-  gload();
-  lstore(0);
-  __syncthreads();
-  int cur = 0;
-  for (int ks = 0; ks < nsteps; ++ks) {
-    const bool more = ks + 1 < nsteps;
-    if (more) gload();
-    const T* su = smem + cur * (KP * BCO + PXMAX * BCI);
-    const T* sx = su + KP * BCO;
-    if constexpr (sizeof(T) == 2) {
-      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-      const int grp16 = (lane >> 4) & 1, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
-#pragma unroll
-      for (int kk = 0; kk < KP / 16; ++kk) {
-        const int k0 = kk * 16 + 8 * h + q;      // this lane supplies the address of K row k0 (and k0+4)
-        bf16x8_t fa[FA];
-#pragma unroll
-        for (int f = 0; f < FA; ++f) {
-          const int ch = wco * (BCO / 2) + 32 * f + 16 * grp16 + 4 * pp;
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + k0 * BCO + ch));
-          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + (k0 + 4) * BCO + ch));
-          s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          fa[f] = __builtin_bit_cast(bf16x8_t, v);
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          bf16x8_t fb[FB];
-#pragma unroll
-          for (int f = 0; f < FB; ++f) {
-            const int ch = wci * (BCI / 2) + 32 * f + 16 * grp16 + 4 * pp;
-            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + (k0 * st + s) * BCI + ch));
-            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + ((k0 + 4) * st + s) * BCI + ch));
-            s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            fb[f] = __builtin_bit_cast(bf16x8_t, v);
-          }
-#pragma unroll
-          for (int i = 0; i < FA; ++i)
-#pragma unroll
-            for (int j = 0; j < FB; ++j)
-              acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[s][i][j], 0, 0, 0);
-        }
-      }
-    } else {
-#pragma unroll 2
-      for (int k = 0; k < KP; k += 2) {
-        float fa[FA];
-#pragma unroll
-        for (int f = 0; f < FA; ++f) fa[f] = su[(k + h) * BCO + wco * (BCO / 2) + 32 * f + r32];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          float fb[FB];
-#pragma unroll
-          for (int f = 0; f < FB; ++f) fb[f] = sx[((k + h) * st + s) * BCI + wci * (BCI / 2) + 32 * f + r32];
-#pragma unroll
-          for (int i = 0; i < FA; ++i)
-#pragma unroll
-            for (int j = 0; j < FB; ++j)
-              acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[s][i][j], 0, 0, 0);
-        }
-      }
-    }
-    if (more) lstore(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  const long long ldw = 9ll * a.Cin;
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int i = 0; i < FA; ++i)
-#pragma unroll
-      for (int j = 0; j < FB; ++j) {
-        const int ci = ci0 + wci * (BCI / 2) + 32 * j + r32;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int co = co0 + wco * (BCO / 2) + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (long long)co * ldw + (r * 3 + s) * a.Cin + ci, acc[s][i][j][reg]);
-        }
-      }
-}
-
 template <typename T>
 static int wg_launch_im2col(WGArgs& a, hipStream_t st) {
   const bool big_co = a.Cout > 64;
@@ -506,9 +320,7 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   const int bco = big_co ? 128 : 64, bci = big_ci ? 128 : 64;
   const int nco_t = (a.Cout + bco - 1) / bco;
   a.nci_t = (a.Cin + bci - 1) / bci;
-  static const bool no_wg3 = getenv("DG_WG_ROW3") == nullptr;   // row-of-taps kernel is opt-in: measured slower than per-tap (register pressure)
-  const bool use3 = !no_wg3 && getenv("DG_WG_GENERIC") == nullptr && a.Wo % 32 == 0 && sizeof(T) == 2;   // bf16 only (fp32 tiles exceed the LDS budget)
-  const int ntiles = nco_t * (use3 ? 3 : 9) * a.nci_t;
+  const int ntiles = nco_t * 9 * a.nci_t;
   static const int target_blocks = getenv("DG_WG_BLOCKS") ? atoi(getenv("DG_WG_BLOCKS")) : 2304;   // 3 resident workgroups x 256 CUs x 3 rounds
   int splits = (target_blocks + ntiles - 1) / ntiles;
   const int max_splits = (a.Mpix + 255) / 256;
@@ -517,15 +329,6 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   a.ppb = ((a.Mpix + splits - 1) / splits + 63) / 64 * 64;
   splits = (a.Mpix + a.ppb - 1) / a.ppb;
   dim3 grid(ntiles, splits);
-  if constexpr (sizeof(T) == 2) {
-    if (use3) {
-      if (big_co && big_ci) hipLaunchKernelGGL((wg3_kernel<T, 128, 128>), grid, dim3(256), 0, st, a);
-      else if (big_co) hipLaunchKernelGGL((wg3_kernel<T, 128, 64>), grid, dim3(256), 0, st, a);
-      else if (big_ci) hipLaunchKernelGGL((wg3_kernel<T, 64, 128>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((wg3_kernel<T, 64, 64>), grid, dim3(256), 0, st, a);
-      return dg_check_launch();
-    }
-  }
   static const bool no_rowstep = getenv("DG_WG_GENERIC") != nullptr;
   const bool rs = !no_rowstep && a.Wo % 32 == 0;
   // 64-pixel K-steps halve the barrier count; they need Wo % 64 == 0 and 2 x 64 x (BCO+BCI) elements of LDS

@@ -121,7 +121,7 @@ int dg_gather_gemm(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, co
                    void* stream);
 
 /* Which kernel variants the calling thread's last dg_conv3x3_fwd / _dgrad launched (bit mask: 1 generic
- * gather-GEMM, 2 fast path, 4 LDS-DMA variant, 8 halo-patch kernel, 16 im2col small-Cin kernel). Diagnostic. */
+ * gather-GEMM, 2 fast path, 8 halo-patch kernel, 16 im2col small-Cin kernel). Diagnostic. */
 int dg_last_conv_kernels(void);
 
 /* Host-only planner (no GPU needed): lowers a layer to its gather-GEMM descriptor(s).
