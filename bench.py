@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gradient exchange goes over gloo")
     args = ap.parse_args()
 
     import torch
@@ -121,9 +123,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    dist = Dist("nccl") if world > 1 else None
+    dist = Dist("gloo" if args.rehearse_on_one_gpu else "nccl") if world > 1 else None
     rank = dist.rank if dist else 0
-    local = dist.local_rank if dist else 0
+    local = 0 if args.rehearse_on_one_gpu else (dist.local_rank if dist else 0)
     torch.cuda.set_device(local)
     B, S, F_, cin, nrb = WORKLOADS[args.workload]
     if args.batch:
@@ -154,7 +156,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64).cuda()
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = t if args.rehearse_on_one_gpu else t.cuda()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     scal = eng.read_scalars(True)
