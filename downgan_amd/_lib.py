@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdowngan_hip.so")
+LIB_PATH = os.environ.get("DG_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libdowngan_hip.so")   # override: A/B builds in tools/
 
 DG_F32, DG_BF16 = 0, 1
 STATUS = {0: "DG_OK", -1: "DG_ERR_BAD_SHAPE", -2: "DG_ERR_BAD_DTYPE", -3: "DG_ERR_BAD_ARG", -4: "DG_ERR_LAUNCH"}
