@@ -578,6 +578,185 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
   }
 }
 
+// Halo kernel with 128-channel K-steps (16 chunks = 256-byte LDS rows).  In-kernel cycle stamps of the 64-channel
+// version show ~700-900 cycles per tap-step that do not shrink with the MFMA work (LDS store + barrier skew between
+// the two waves of a SIMD + scalar bookkeeping), against 1024 MFMA-pipe cycles: doubling the channels per step
+// doubles the MFMA work those fixed costs are amortised over.  The patch is single-buffered (83 KB) and swapped
+// at the channel-block boundary between two barriers; weights use two 32-KB slots with a register prefetch.
+template <typename T>
+__global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
+  constexpr int BC = 128, KC = 16;                                       // 16 chunks per row
+  constexpr int NPL = (PROWS * KC + 511) / 512;                          // 11 patch chunks per thread
+  constexpr int NWL = BC * KC / 512;                                     // 4 weight chunks per thread
+  extern __shared__ __attribute__((aligned(16))) uint4 dsm[];
+  uint4* const s_patch = dsm;                    // [PROWS][16]
+  uint4* const s_w = dsm + PROWS * KC;           // [2][BC][16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tile_c = tile % a.nct;
+  unsigned rest = tile / a.nct;
+  const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
+  const int ty0 = (rest % tiles_y) * TH;
+  const int img = rest / tiles_y;
+  const int c0 = tile_c * BC;
+  const int cc = tid & 15, r0 = tid >> 4;        // r0 in [0,32)
+
+  const int sy_base = ty0 - 1 > 0 ? ty0 - 1 : 0;
+  unsigned poff[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int pr = r0 + 32 * i;
+    const int py = pr / PW, px = pr - py * PW;
+    const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+    const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+    poff[i] = ok ? (unsigned)(((long long)(sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
+  }
+  unsigned woff[NWL];
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    const int row = r0 + 32 * i;
+    woff[i] = (c0 + row < a.Nout) ? (unsigned)((long long)row * a.ldw * ES) + cc * 16 : DG_OOB_OFF;
+  }
+  const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
+  const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
+
+  u32x4_t rp[NPL], rw[NWL];
+  auto load_patch = [&](int cb) {
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, poff[i], 0, 0);
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0 + 32 * i;
+      if (pr < PROWS) s_patch[pr * KC + (cc ^ (pr & 15))] = __builtin_bit_cast(uint4, rp[i]);
+    }
+  };
+  auto load_w = [&](int cb, int tap) {
+    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
+    const long long wo = (long long)(code >> 4) * a.Cred + cb * KC * EPC;
+    __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + wo * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rwd, woff[i], 0, 0);
+  };
+  auto store_w = [&](int slot) {
+    uint4* s = s_w + slot * BC * KC;
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int row = r0 + 32 * i;
+      s[row * KC + (cc ^ (row & 15))] = __builtin_bit_cast(uint4, rw[i]);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int wp = wave & 3, wc = wave >> 2;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ncb = a.cch / KC, ntaps = a.ntaps;
+  const int nsteps = ncb * ntaps;
+
+  auto read_frags = [&](uint4 (&fa)[4], uint4 (&fb)[4], int prow0, int slot, int kk) {
+    const uint4* sw = s_w + slot * BC * KC;
+    const int ch = kk * 4 + g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wc * 64 + 16 * j + l15;
+      fa[j] = sw[row * KC + (ch ^ (row & 15))];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pr = prow0 + i * PW;
+      fb[i] = s_patch[pr * KC + (ch ^ (pr & 15))];
+    }
+  };
+  auto mma_block = [&](const uint4 (&fa)[4], const uint4 (&fb)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
+  };
+
+  load_patch(0);
+  load_w(0, 0);
+  store_patch();
+  store_w(0);
+  __syncthreads();
+
+  uint4 fa0[4], fb0[4], fa1[4], fb1[4];
+  int cb = 0, tap = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    int ntap = tap + 1, ncbn = cb;
+    if (ntap == ntaps) { ntap = 0; ncbn = cb + 1; }
+    if (more) load_w(ncbn, ntap);
+    if (tap == 0 && cb + 1 < ncb) load_patch(cb + 1);
+    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
+    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
+    const int prow0 = (wp * 4 + 1 + dy) * PW + 1 + dx + l15;
+    const int slot = s & 1;
+    read_frags(fa0, fb0, prow0, slot, 0);
+    read_frags(fa1, fb1, prow0, slot, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_block(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(fa0, fb0, prow0, slot, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_block(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(fa1, fb1, prow0, slot, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_block(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_block(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store_w(slot ^ 1);
+    if (ntap == 0 && more) {          // channel-block boundary: swap the single-buffered patch between two barriers
+      __syncthreads();
+      store_patch();
+    }
+    __syncthreads();
+    tap = ntap; cb = ncbn;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gy = ty0 + wp * 4 + i, gx = tx0 + l15;
+    if (gy >= a.Hg || gx >= a.Wg) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co0 = c0 + wc * 64 + 16 * j + 4 * g;
+      if (co0 >= a.Nout) continue;
+      gg_store_frag<T>(a, acc[j][i], img, gy, gx, co0);
+    }
+  }
+}
+
+template <typename T>
+static int gg_launch_halo128(GGArgs& a, int N, hipStream_t st) {
+  constexpr int LDS_BYTES = (324 + 2 * 128) * 16 * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return DG_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
+  a.nct = (unsigned)((a.Nout + 127) / 128);
+  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  g_last_kinds |= 8;
+  hipLaunchKernelGGL((gg_halo128_kernel<T>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+  return dg_check_launch();
+}
+
 template <typename T>
 static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
   constexpr int LDS_BYTES = (2 * 324 + 3 * 128) * 8 * 16;
@@ -737,7 +916,11 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   // the patch is sized for tap shifts in [-1, 1] around a unit-stride grid (stride-1 forward, all data gradients)
   if (!no_halo && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 &&
       a.Hs == a.Hg && a.Ws == a.Wg)
+  {
+    static const bool no128 = getenv("DG_GG_HALO64") != nullptr;
+    if (!no128 && a.cch % 16 == 0) return gg_launch_halo128<T>(a, N, st);
     return gg_launch_halo<T>(a, N, st);
+  }
   if (a.Nout > 64) return gg_launch_t<T, 128, 128, 64, 64>(a, st);
   if (a.Nout > 32) return gg_launch_t<T, 128, 64, 64, 32>(a, st);
   if (a.Nout > 16) return gg_launch_t<T, 128, 32, 32, 32>(a, st);
