@@ -393,6 +393,123 @@ __global__ __launch_bounds__(256) void gg_fast_kernel(const GGArgs a) {
   gg_epilogue<T, BP, BC, WP, WC>(a, acc, p0, c0, wp, wc, l15, g);
 }
 
+// ---- Epilogue of the halo kernels.  The lane's 16 fragments (pixel fragment i = tile row wp*4+i, channel
+// fragment j) sit at (relative pixel of i + pixel-shuffle offset of j) * ld + channel: every tensor is addressed
+// through a raw buffer descriptor based at the workgroup's first destination pixel plus 32-bit per-lane offsets
+// (one multiply-add per fragment and tensor instead of 64-bit index arithmetic), and out-of-tile / out-of-range
+// fragments get an out-of-range offset: the hardware drops those stores and returns zeros for those loads, so the
+// epilogue has no divergent branches.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+template <typename T> struct EpiIO;
+template <> struct EpiIO<bf16_t> {
+  typedef u32x2_t V;
+  static __device__ __forceinline__ V load(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+  static __device__ __forceinline__ void store(const float* v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    V t;
+    t[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    t[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, off, 0, 0);
+  }
+  static __device__ __forceinline__ void unpack(const V& t, float* v) {
+    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+  }
+};
+template <> struct EpiIO<float> {
+  typedef u32x4_t V;
+  static __device__ __forceinline__ V load(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+  static __device__ __forceinline__ void store(const float* v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    V t;
+    t[0] = __float_as_uint(v[0]); t[1] = __float_as_uint(v[1]); t[2] = __float_as_uint(v[2]); t[3] = __float_as_uint(v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, 0);
+  }
+  static __device__ __forceinline__ void unpack(const V& t, float* v) {
+    v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]); v[2] = __uint_as_float(t[2]); v[3] = __uint_as_float(t[3]);
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4][4], int img, int ty0, int tx0, int c0, int wp,
+                                              int wc, int l15, int g) {
+  typedef EpiIO<T> IO;
+  typedef typename IO::V V;
+  constexpr int ES = (int)sizeof(T);
+  const int psm = a.dst_ps ? 2 : a.dy_mul, psx = a.dst_ps ? 2 : a.dx_mul;
+  const int oy = a.dst_ps ? 0 : a.dy_off, ox = a.dst_ps ? 0 : a.dx_off;
+  // workgroup base pixel (scalar) and this lane's relative pixel for tile row wp*4 (+ i rows of pitch `rowp`)
+  const long long pb = ((long long)img * a.Hd + (long long)ty0 * psm + oy) * a.Wd + (long long)tx0 * psx + ox;
+  const int rel0 = (wp * 4) * psm * a.Wd + l15 * psx;
+  const int rowp = psm * a.Wd;
+  int cc[4], pj[4];
+  bool cok[4];
+  float4 bias[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cj = c0 + wc * 64 + 16 * j + 4 * g;
+    cok[j] = cj < a.Nout;
+    bias[j] = (a.bias && cok[j]) ? *reinterpret_cast<const float4*>(a.bias + cj) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.dst_ps) {
+      const int q = cj / a.cps_dst;
+      cc[j] = cj - q * a.cps_dst; pj[j] = (q >> 1) * a.Wd + (q & 1);
+    } else { cc[j] = cj; pj[j] = 0; }
+  }
+  const bool xok = tx0 + l15 < a.Wg;
+  auto rsrc = [&](const void* p, long long ld) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + pb * ld * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rY = rsrc(a.y, a.ldy);
+  const __amdgpu_buffer_rsrc_t r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1), r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2),
+                               rm = rsrc(a.mask ? a.mask : a.y, a.ldmask);
+  const int ldy = (int)a.ldy, ld1 = (int)a.ldr1, ld2 = (int)a.ldr2, ldm = (int)a.ldmask;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool pok = xok && ty0 + wp * 4 + i < a.Hg;
+    const int rel = rel0 + i * rowp;
+    unsigned oyv[4];
+    V v1[4], v2[4], vm[4], va[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = pok && cok[j];
+      const int pix = rel + pj[j];
+      oyv[j] = ok ? (unsigned)((pix * ldy + cc[j]) * ES) : DG_OOB_OFF;
+      if (a.r1) v1[j] = IO::load(r1, ok ? (unsigned)((pix * ld1 + cc[j]) * ES) : DG_OOB_OFF);
+      if (a.r2) v2[j] = IO::load(r2, ok ? (unsigned)((pix * ld2 + cc[j]) * ES) : DG_OOB_OFF);
+      if (a.mask) vm[j] = IO::load(rm, ok ? (unsigned)((pix * ldm + cc[j]) * ES) : DG_OOB_OFF);
+      if (a.accumulate) va[j] = IO::load(rY, oyv[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[j][i][0] + bias[j].x, acc[j][i][1] + bias[j].y, acc[j][i][2] + bias[j].z, acc[j][i][3] + bias[j].w};
+      float r[4];
+      if (a.has_act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], a.act_slope);
+      }
+      if (a.r1) {
+        IO::unpack(v1[j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s1 + r[e];
+      }
+      if (a.r2) {
+        IO::unpack(v2[j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
+      }
+      if (a.mask) {
+        IO::unpack(vm[j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
+      }
+      if (a.accumulate) {
+        IO::unpack(va[j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      IO::store(v, rY, oyv[j]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Halo path (unit-stride gathers: stride-1 forward, every data gradient).  One workgroup = a 16x16 tile of
 // the GEMM-row grid of ONE image x 128 output channels, 8 waves (wave = 4 tile rows x 64 channels).
@@ -565,17 +682,7 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
     if (s + 1 < nsteps) step(s + 1, rwb, rwa);
   }
 
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gy = ty0 + wp * 4 + i, gx = tx0 + l15;
-    if (gy >= a.Hg || gx >= a.Wg) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int co0 = c0 + wc * 64 + 16 * j + 4 * g;
-      if (co0 >= a.Nout) continue;
-      gg_store_frag<T>(a, acc[j][i], img, gy, gx, co0);
-    }
-  }
+  halo_epilogue<T>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
 }
 
 // Halo kernel with 128-channel K-steps (16 chunks = 256-byte LDS rows).  In-kernel cycle stamps of the 64-channel
@@ -727,17 +834,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
     tap = ntap; cb = ncbn;
   }
 
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gy = ty0 + wp * 4 + i, gx = tx0 + l15;
-    if (gy >= a.Hg || gx >= a.Wg) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int co0 = c0 + wc * 64 + 16 * j + 4 * g;
-      if (co0 >= a.Nout) continue;
-      gg_store_frag<T>(a, acc[j][i], img, gy, gx, co0);
-    }
-  }
+  halo_epilogue<T>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
 }
 
 template <typename T>
