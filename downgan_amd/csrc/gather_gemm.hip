@@ -40,6 +40,38 @@ struct GGArgs {
   unsigned nwg, nct;
 };
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#define DG_OOB_OFF 0x80000000u   // voffset >= num_records: buffer loads return 0, buffer stores are dropped
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+template <typename T> struct EpiIO;
+template <> struct EpiIO<bf16_t> {
+  typedef u32x2_t V;
+  static __device__ __forceinline__ V load(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+  static __device__ __forceinline__ void store(const float* v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    V t;
+    t[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    t[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, off, 0, 0);
+  }
+  static __device__ __forceinline__ void unpack(const V& t, float* v) {
+    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+  }
+};
+template <> struct EpiIO<float> {
+  typedef u32x4_t V;
+  static __device__ __forceinline__ V load(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+  static __device__ __forceinline__ void store(const float* v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    V t;
+    t[0] = __float_as_uint(v[0]); t[1] = __float_as_uint(v[1]); t[2] = __float_as_uint(v[2]); t[3] = __float_as_uint(v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, 0);
+  }
+  static __device__ __forceinline__ void unpack(const V& t, float* v) {
+    v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]); v[2] = __uint_as_float(t[2]); v[3] = __uint_as_float(t[3]);
+  }
+};
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
@@ -55,69 +87,90 @@ template <> struct Mma<float> {
   }
 };
 
-// Epilogue of one accumulator fragment: the lane owns output channels co0..co0+3 of grid pixel (n, gy, gx).
-template <typename T>
-__device__ __forceinline__ void gg_store_frag(const GGArgs& a, const f32x4_t& accv, int n, int gy, int gx, int co0) {
-  T* Y = reinterpret_cast<T*>(a.y);
-  const T* R1 = reinterpret_cast<const T*>(a.r1);
-  const T* R2 = reinterpret_cast<const T*>(a.r2);
-  const T* MK = reinterpret_cast<const T*>(a.mask);
-  int py, px, c;
-  if (a.dst_ps) {
-    const int q = co0 / a.cps_dst;
-    c = co0 - q * a.cps_dst;
-    py = gy * 2 + (q >> 1); px = gx * 2 + (q & 1);
-  } else {
-    c = co0; py = gy * a.dy_mul + a.dy_off; px = gx * a.dx_mul + a.dx_off;
-  }
-  const long long pix = ((long long)n * a.Hd + py) * a.Wd + px;
-  float v[4] = {accv[0], accv[1], accv[2], accv[3]};
-  if (a.bias) {
-    const float4 b = *reinterpret_cast<const float4*>(a.bias + co0);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-  }
-  if (a.has_act) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], a.act_slope);
-  }
-  if (R1) {
-    float r[4]; ld4(R1 + pix * a.ldr1 + c, r);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s1 + r[e];
-  }
-  if (R2) {
-    float r[4]; ld4(R2 + pix * a.ldr2 + c, r);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
-  }
-  if (MK) {
-    float r[4]; ld4(MK + pix * a.ldmask + c, r);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
-  }
-  if (a.accumulate) {
-    float r[4]; ld4(Y + pix * a.ldy + c, r);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += r[e];
-  }
-  st4(Y + pix * a.ldy + c, v);
-}
-
+// ---- Epilogue of the row-tiled kernels (generic / fast / im2col): like halo_epilogue below, every tensor is
+// addressed through a raw buffer descriptor based at the destination pixel of the workgroup's first row plus
+// 32-bit per-lane offsets; rows past M / channels past Nout get an out-of-range offset (stores dropped).
 template <typename T, int BP, int BC, int WP, int WC>
 __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC / 16][WP / 16], int p0, int c0, int wp, int wc,
                                             int l15, int g) {
+  typedef EpiIO<T> IO;
+  typedef typename IO::V V;
   constexpr int FP = WP / 16, FC = WC / 16;
+  constexpr int ES = (int)sizeof(T);
+  auto dest_pixel = [&](int m) -> long long {
+    const int gx = m % a.Wg, t = m / a.Wg;
+    const int gy = t % a.Hg, n = t / a.Hg;
+    const int py = a.dst_ps ? gy * 2 : gy * a.dy_mul + a.dy_off;
+    const int px = a.dst_ps ? gx * 2 : gx * a.dx_mul + a.dx_off;
+    return ((long long)n * a.Hd + py) * a.Wd + px;
+  };
+  const long long pb = dest_pixel(p0);                 // workgroup-uniform
+  int cc[FC], pj[FC];
+  bool cok[FC];
+  float4 bias[FC];
+#pragma unroll
+  for (int j = 0; j < FC; ++j) {
+    const int cj = c0 + wc * WC + 16 * j + 4 * g;
+    cok[j] = cj < a.Nout;
+    bias[j] = (a.bias && cok[j]) ? *reinterpret_cast<const float4*>(a.bias + cj) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.dst_ps) {
+      const int q = cj / a.cps_dst;
+      cc[j] = cj - q * a.cps_dst; pj[j] = (q >> 1) * a.Wd + (q & 1);
+    } else { cc[j] = cj; pj[j] = 0; }
+  }
+  auto rsrc = [&](const void* p, long long ld) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + pb * ld * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rY = rsrc(a.y, a.ldy);
+  const __amdgpu_buffer_rsrc_t r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1), r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2),
+                               rm = rsrc(a.mask ? a.mask : a.y, a.ldmask);
+  const int ldy = (int)a.ldy, ld1 = (int)a.ldr1, ld2 = (int)a.ldr2, ldm = (int)a.ldmask;
 #pragma unroll
   for (int i = 0; i < FP; ++i) {
     const int m = p0 + wp * WP + 16 * i + l15;
-    if (m >= a.M) continue;
-    const int gx = m % a.Wg, t = m / a.Wg;
-    const int gy = t % a.Hg, n = t / a.Hg;
+    const bool pok = m < a.M;
+    const int rel = pok ? (int)(dest_pixel(m) - pb) : 0;
+    unsigned oyv[FC];
+    V v1[FC], v2[FC], vm[FC], va[FC];
 #pragma unroll
     for (int j = 0; j < FC; ++j) {
-      const int co0 = c0 + wc * WC + 16 * j + 4 * g;
-      if (co0 >= a.Nout) continue;
-      gg_store_frag<T>(a, acc[j][i], n, gy, gx, co0);
+      const bool ok = pok && cok[j];
+      const int pix = rel + pj[j];
+      oyv[j] = ok ? (unsigned)((pix * ldy + cc[j]) * ES) : DG_OOB_OFF;
+      if (a.r1) v1[j] = IO::load(r1, ok ? (unsigned)((pix * ld1 + cc[j]) * ES) : DG_OOB_OFF);
+      if (a.r2) v2[j] = IO::load(r2, ok ? (unsigned)((pix * ld2 + cc[j]) * ES) : DG_OOB_OFF);
+      if (a.mask) vm[j] = IO::load(rm, ok ? (unsigned)((pix * ldm + cc[j]) * ES) : DG_OOB_OFF);
+      if (a.accumulate) va[j] = IO::load(rY, oyv[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < FC; ++j) {
+      float v[4] = {acc[j][i][0] + bias[j].x, acc[j][i][1] + bias[j].y, acc[j][i][2] + bias[j].z, acc[j][i][3] + bias[j].w};
+      float r[4];
+      if (a.has_act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], a.act_slope);
+      }
+      if (a.r1) {
+        IO::unpack(v1[j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s1 + r[e];
+      }
+      if (a.r2) {
+        IO::unpack(v2[j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
+      }
+      if (a.mask) {
+        IO::unpack(vm[j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
+      }
+      if (a.accumulate) {
+        IO::unpack(va[j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      IO::store(v, rY, oyv[j]);
     }
   }
 }
@@ -254,11 +307,9 @@ __global__ __launch_bounds__(256) void gg_kernel(const GGArgs a) {
 // its rows and a 9-bit tap-validity mask.  Operands are fetched with raw buffer loads whose
 // descriptor base is re-pointed per K-step (scalar adds); a padded / out-of-tile row simply gets an
 // out-of-range offset and the hardware returns zeros - no per-row address arithmetic in the loop.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-#define DG_OOB_OFF 0x80000000u
 
 template <typename T, int BP, int BC, int WP, int WC>
-__global__ __launch_bounds__(256) void gg_fast_kernel(const GGArgs a) {
+__global__ __launch_bounds__(256, 2) void gg_fast_kernel(const GGArgs a) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int ES = (int)sizeof(T);
   constexpr int NPW = BP / WP;
@@ -399,35 +450,6 @@ __global__ __launch_bounds__(256) void gg_fast_kernel(const GGArgs a) {
 // (one multiply-add per fragment and tensor instead of 64-bit index arithmetic), and out-of-tile / out-of-range
 // fragments get an out-of-range offset: the hardware drops those stores and returns zeros for those loads, so the
 // epilogue has no divergent branches.
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-template <typename T> struct EpiIO;
-template <> struct EpiIO<bf16_t> {
-  typedef u32x2_t V;
-  static __device__ __forceinline__ V load(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
-  static __device__ __forceinline__ void store(const float* v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-    V t;
-    t[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-    t[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-    __builtin_amdgcn_raw_buffer_store_b64(t, r, off, 0, 0);
-  }
-  static __device__ __forceinline__ void unpack(const V& t, float* v) {
-    v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
-    v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
-  }
-};
-template <> struct EpiIO<float> {
-  typedef u32x4_t V;
-  static __device__ __forceinline__ V load(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
-  static __device__ __forceinline__ void store(const float* v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-    V t;
-    t[0] = __float_as_uint(v[0]); t[1] = __float_as_uint(v[1]); t[2] = __float_as_uint(v[2]); t[3] = __float_as_uint(v[3]);
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, 0);
-  }
-  static __device__ __forceinline__ void unpack(const V& t, float* v) {
-    v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]); v[2] = __uint_as_float(t[2]); v[3] = __uint_as_float(t[3]);
-  }
-};
-
 template <typename T>
 __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4][4], int img, int ty0, int tx0, int c0, int wp,
                                               int wc, int l15, int g) {
@@ -879,7 +901,7 @@ static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
 // padded channels, the weight tile is built once per workgroup, and each workgroup streams several
 // 128-pixel tiles.
 template <typename T>
-__global__ __launch_bounds__(256) void gg_im2col_kernel(const GGArgs a, int tiles_per_block) {
+__global__ __launch_bounds__(256, 2) void gg_im2col_kernel(const GGArgs a, int tiles_per_block) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int KCH = 32 / EPC;         // 16-B chunks per 32-element K row
   constexpr int TPC = EPC / 2;          // taps per chunk (2 channels per tap)
