@@ -41,7 +41,12 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
   constexpr int NU = KP * CPRU / 256, NX = KP * CPRX / 256;   // 16-B chunks per thread
   static_assert(NU >= 1 && NX >= 1, "tile too small");
   constexpr int FA = BCO / 64, FB = BCI / 64;    // 32x32 fragments per wave (2x2 waves)
-  __shared__ __attribute__((aligned(16))) T smem[2 * KP * (BCO + BCI)];
+  // bf16 rows are padded by 64 B: with 256-B (or 128-B) rows every K row of a ds_read_b64_tr_b16 block lands on the same
+  // banks (4-way conflict, measured 60 % of LDS cycles); a pitch of 64 B mod 256 B spreads the 32 lanes of a half-wave
+  // (2 column groups x 4 rows x 4 column quads, 8 B each) over all 64 banks.
+  constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
+  constexpr int LDU = BCO + PADE, LDX = BCI + PADE;
+  __shared__ __attribute__((aligned(16))) T smem[2 * KP * (LDU + LDX)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = blockIdx.x;
@@ -187,17 +192,17 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
     if constexpr (ROWSTEP) gload_row(); else gload_gen(pb);
   };
   auto lstore = [&](int buf) {
-    T* su = smem + buf * KP * (BCO + BCI);
-    T* sx = su + KP * BCO;
+    T* su = smem + buf * KP * (LDU + LDX);
+    T* sx = su + KP * LDU;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const int e = tid + 256 * i, row = e / CPRU, col = e % CPRU;
-      *reinterpret_cast<uint4*>(su + row * BCO + col * EPC) = ru[i];
+      *reinterpret_cast<uint4*>(su + row * LDU + col * EPC) = ru[i];
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int e = tid + 256 * i, row = e / CPRX, col = e % CPRX;
-      *reinterpret_cast<uint4*>(sx + row * BCI + col * EPC) = rx[i];
+      *reinterpret_cast<uint4*>(sx + row * LDX + col * EPC) = rx[i];
     }
   };
 
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
   for (int ks = 0; ks < nsteps; ++ks) {
     const bool more = ks + 1 < nsteps;
     if (more) gload(pbeg + (ks + 1) * KP);
-    const T* su = smem + cur * KP * (BCO + BCI);
-    const T* sx = su + KP * BCO;
+    const T* su = smem + cur * KP * (LDU + LDX);
+    const T* sx = su + KP * LDU;
     if constexpr (sizeof(T) == 2) {
       // lane -> (row q of a 4x16 block, column group pp) address for the transposed read
       const int grp16 = (lane >> 4) & 1, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
@@ -233,8 +238,8 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
         for (int f = 0; f < FA; ++f) {
           const int ch = wco * (BCO / 2) + 32 * f + 16 * grp16 + 4 * pp;
           const int k0 = kk * 16 + 8 * h + q;
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + k0 * BCO + ch));
-          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + (k0 + 4) * BCO + ch));
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + k0 * LDU + ch));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + (k0 + 4) * LDU + ch));
           typedef __attribute__((ext_vector_type(8))) short s16x8_t;
           s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           fa[f] = __builtin_bit_cast(bf16x8_t, v);
@@ -243,8 +248,8 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
         for (int f = 0; f < FB; ++f) {
           const int ch = wci * (BCI / 2) + 32 * f + 16 * grp16 + 4 * pp;
           const int k0 = kk * 16 + 8 * h + q;
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + k0 * BCI + ch));
-          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + (k0 + 4) * BCI + ch));
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + k0 * LDX + ch));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + (k0 + 4) * LDX + ch));
           typedef __attribute__((ext_vector_type(8))) short s16x8_t;
           s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           fb[f] = __builtin_bit_cast(bf16x8_t, v);
@@ -260,9 +265,9 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
       for (int k = 0; k < KP; k += 2) {
         float fa[FA], fb[FB];
 #pragma unroll
-        for (int f = 0; f < FA; ++f) fa[f] = su[(k + h) * BCO + wco * (BCO / 2) + 32 * f + r32];
+        for (int f = 0; f < FA; ++f) fa[f] = su[(k + h) * LDU + wco * (BCO / 2) + 32 * f + r32];
 #pragma unroll
-        for (int f = 0; f < FB; ++f) fb[f] = sx[(k + h) * BCI + wci * (BCI / 2) + 32 * f + r32];
+        for (int f = 0; f < FB; ++f) fb[f] = sx[(k + h) * LDX + wci * (BCI / 2) + 32 * f + r32];
 #pragma unroll
         for (int i = 0; i < FA; ++i)
 #pragma unroll
@@ -333,7 +338,7 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   const bool rs = !no_rowstep && a.Wo % 32 == 0;
   // 64-pixel K-steps halve the barrier count; they need Wo % 64 == 0 and 2 x 64 x (BCO+BCI) elements of LDS
   static const bool no_kp64 = getenv("DG_WG_KP32") != nullptr;
-  const bool kp64 = rs && !no_kp64 && a.Wo % 64 == 0 && a.ppb % 64 == 0 && sizeof(T) == 2;
+  const bool kp64 = rs && !no_kp64 && a.Wo % 64 == 0 && a.ppb % 64 == 0 && sizeof(T) == 2 && !(big_co && big_ci);   // padded 128x128 tiles: 64-pixel steps exceed 64 KB of static LDS
 #define WG_LAUNCH(BCO, BCI)                                                                           \
   do {                                                                                                \
     if (kp64) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, true, 64>), grid, dim3(256), 0, st, a); } \
