@@ -171,7 +171,8 @@ def main():
             a[0] += flops; a[1] += s_ev.elapsed_time(e_ev) * 1e-3; a[2] += 1
         for tag, (fl, sec, n) in agg.items():
             kernels[tag] = {"launches": n, "seconds": round(sec, 4), "tflops": round(fl / sec / 1e12, 2) if sec > 0 else None}
-        # dominant kernel: gg_halo_kernel (stride-1 conv forward + stride-1 data gradient).  Only calls that were
+        # dominant kernel: gg_halo128_kernel (stride-1 conv forward + stride-1 data gradient; gg_halo_kernel is its
+        # 64-channel-step sibling for Cred % 128 != 0, not used at cfg2).  Only calls that were
         # served by that kernel alone (tag suffix k8) are counted, so achieved = algorithmic flops of those
         # launches / their summed launch durations, and launches/seconds give the average launch duration.
         halo = [t for t in agg if t.endswith(":k8")]
@@ -180,7 +181,7 @@ def main():
         nl = sum(agg[t][2] for t in halo)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         ach = fl / sec / 1e12 if sec > 0 else 0.0
-        roofline = {"kernel": "gg_halo_kernel (implicit-GEMM conv3x3, stride-1 forward + data-gradient)", "bound": "mfma",
+        roofline = {"kernel": "gg_halo128_kernel (implicit-GEMM conv3x3, stride-1 forward + data-gradient)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "launches": nl, "avg_launch_ms": round(sec / max(nl, 1) * 1e3, 4),
                     "share_of_step": round(sec / elapsed, 3)}
