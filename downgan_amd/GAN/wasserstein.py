@@ -83,6 +83,13 @@ class WassersteinGAN:
         o.gp_finish(e.ss, B, B * e.world, e.hp.gp_lambda, 0.0, e.coef, e._sc("gp_ret"))
         return float(e._sc("gp_ret").item())
 
+    def gen_batch_and_log_metrics(self, coarse, fine):
+        """Native version of mlflow_tools/mlflow_epoch.py:53-63 (the per-step metrics pass, wasserstein.py:140):
+        returns {"MAE", "MSE", "Wass", "MSSSIM": None}."""
+        e = self._eng(coarse, fine)
+        xc, xf = self._to_native(e, coarse, fine)
+        return e.metrics_pass(xc, xf)
+
     def _train_epoch(self, dataloader, testdataloader=None, epoch=0):
         """wasserstein.py:120-147 without the metrics / plotting / checkpoint side effects."""
         log = []

@@ -61,6 +61,7 @@ _PROTOS = {
     "dg_gp_finish": [_vp, _i, _i, _f, _f, _vp, _vp, _vp],
     "dg_scale_rows": [_i, _vp, _vp, _vp, _i, _i64, _vp],
     "dg_l1": [_i, _vp, _i64, _vp, _i64, _i64, _i, _vp, _vp, _i64, _f, _vp, _i64, _vp],
+    "dg_sqdiff": [_i, _vp, _i64, _vp, _i64, _i64, _i, _vp, _vp],
     "dg_sum_strided": [_vp, _i, _i, _f, _vp, _vp],
     "dg_fill_col": [_vp, _i, _i, _i, _f, _vp],
     "dg_adam": [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp],

@@ -175,7 +175,7 @@ extern "C" int dg_gp_finish(const float* ss, int B, int B_global, float gp_lambd
 }
 
 // ------------------------------------------------------------------ L1 content loss + gradient
-template <typename T>
+template <typename T, bool SQ>   // SQ: accumulate (a-b)^2 instead of |a-b| (MSE metric); no gradient in that mode
 __global__ void l1_kernel(const T* a, long long lda, const T* b, long long ldb, long long rows, int cchunks, float* acc,
                           T* grad, long long ldg, float gscale, const T* addend, long long ldadd) {
   constexpr int EPC = DT<T>::EPC;
@@ -190,7 +190,7 @@ __global__ void l1_kernel(const T* a, long long lda, const T* b, long long ldb, 
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       const float d = av[e] - bv[e];
-      s += fabsf(d);
+      s += SQ ? d * d : fabsf(d);
       gv[e] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
     }
     if (grad) {
@@ -217,8 +217,22 @@ extern "C" int dg_l1(int dtype, const void* a, int64_t lda, const void* b, int64
   long long nb = (rows * (C / epc) + 256 * 8 - 1) / (256 * 8);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
-  if (dtype == DG_F32) hipLaunchKernelGGL(l1_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, rows, C / 4, acc, (float*)grad, ldg, grad_scale, (const float*)addend, ldadd);
-  else if (dtype == DG_BF16) hipLaunchKernelGGL(l1_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, rows, C / 8, acc, (bf16_t*)grad, ldg, grad_scale, (const bf16_t*)addend, ldadd);
+  if (dtype == DG_F32) hipLaunchKernelGGL((l1_kernel<float, false>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, rows, C / 4, acc, (float*)grad, ldg, grad_scale, (const float*)addend, ldadd);
+  else if (dtype == DG_BF16) hipLaunchKernelGGL((l1_kernel<bf16_t, false>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, rows, C / 8, acc, (bf16_t*)grad, ldg, grad_scale, (const bf16_t*)addend, ldadd);
+  else return DG_ERR_BAD_DTYPE;
+  return dg_check_launch();
+}
+
+extern "C" int dg_sqdiff(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int C, float* acc,
+                         void* stream) {
+  if (!a || !b || !acc || rows <= 0 || C <= 0 || C % 8 || lda % 8 || ldb % 8) return DG_ERR_BAD_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int epc = dtype == DG_F32 ? 4 : 8;
+  long long nb = (rows * (C / epc) + 256 * 8 - 1) / (256 * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  if (dtype == DG_F32) hipLaunchKernelGGL((l1_kernel<float, true>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, rows, C / 4, acc, (float*)nullptr, 0ll, 0.f, (const float*)nullptr, 0ll);
+  else if (dtype == DG_BF16) hipLaunchKernelGGL((l1_kernel<bf16_t, true>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, rows, C / 8, acc, (bf16_t*)nullptr, 0ll, 0.f, (const bf16_t*)nullptr, 0ll);
   else return DG_ERR_BAD_DTYPE;
   return dg_check_launch();
 }

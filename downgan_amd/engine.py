@@ -563,6 +563,27 @@ class TrainEngine:
         if apply_update:
             self._allreduce_and_step(G.P)                         # :83
 
+    def metrics_pass(self, coarse, fine):
+        """Per-batch evaluation metrics of the reference's training loop (mlflow_tools/mlflow_epoch.py:53-63 called at
+        wasserstein.py:140): MAE = L1(real, G(x)) (losses.py:40-55), MSE (losses.py:58-70), Wass = mean C(real) -
+        mean C(G(x)) (losses.py:8-9).  MS-SSIM (losses.py:12-38, third-party pytorch_msssim) is not computed natively."""
+        o, C, B = self.ops, self.C, self.B
+        fake = self.G.forward(coarse, save=False)
+        m = self.scal[5:8]
+        m.zero_()
+        o.l1(fine, fake, m[0:1])
+        o.sqdiff(fine, fake, m[1:2])
+        out = C.forward(fine)
+        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
+        out = C.forward(fake)
+        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
+        s = self.scal.detach().cpu().tolist()
+        d = {"l1_sum": s[5], "sq_sum": s[6], "c_real_mean": s[0], "c_fake_mean": s[1]}
+        if self.dist is not None and self.world > 1:
+            d = self.dist.reduce_scalars(d, mean=("c_real_mean", "c_fake_mean"), total=("l1_sum", "sq_sum"))
+        n = self.n_real_elems * self.world
+        return {"MAE": d["l1_sum"] / n, "MSE": d["sq_sum"] / n, "Wass": d["c_real_mean"] - d["c_fake_mean"], "MSSSIM": None}
+
     def train_step(self, coarse, fine, alpha):
         """loop body of _train_epoch, wasserstein.py:131-147 (metrics pass :140 excluded)."""
         self.critic_iteration(coarse, fine, alpha)

@@ -276,6 +276,12 @@ class HipOps:
                              pix_layout(grad)[0] if grad is not None else 0, float(grad_scale), _ptr(addend),
                              pix_layout(addend)[0] if addend is not None else 0, self._stream()), "dg_l1")
 
+    def sqdiff(self, a, b, acc):
+        self._act(a); self._act(b)
+        assert a.shape == b.shape and acc.dtype == torch.float32
+        lda, rows = pix_layout(a)
+        check(self.lib.dg_sqdiff(self.dg, _ptr(a), lda, _ptr(b), pix_layout(b)[0], rows, a.shape[-1], _ptr(acc), self._stream()), "dg_sqdiff")
+
     def sum_strided(self, inp, n, stride, scale, out):
         assert inp.dtype == torch.float32 and out.dtype == torch.float32
         check(self.lib.dg_sum_strided(_ptr(inp), n, stride, float(scale), _ptr(out), self._stream()), "dg_sum_strided")

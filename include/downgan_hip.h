@@ -180,6 +180,10 @@ int dg_scale_rows(int dtype, const void* g, const float* coef, void* out, int B,
 int dg_l1(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int C,
           float* acc, void* grad, int64_t ldg, float grad_scale, const void* addend, int64_t ldadd,
           void* stream);
+/* acc[0] (fp32, pre-zeroed) += sum (a-b)^2 over [rows x C]  (content_MSELoss metric, losses.py:58-70; metrics pass
+ * mlflow_epoch.py:53-63) */
+int dg_sqdiff(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int C,
+              float* acc, void* stream);
 /* out[0] = scale * sum_{i<n} in[i*stride]  (means of critic outputs, wasserstein.py:46-47,74) */
 int dg_sum_strided(const float* in, int n, int stride, float scale, float* out, void* stream);
 /* fill fp32 buffer with a constant on a strided column (grad_outputs=ones, wasserstein.py:103) */

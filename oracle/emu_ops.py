@@ -202,6 +202,9 @@ class EmuOps:
                 g = g + addend.float()
             grad.copy_(g.to(grad.dtype))
 
+    def sqdiff(self, a, b, acc):
+        acc[0] += ((a.float() - b.float()) ** 2).sum()
+
     def sum_strided(self, inp, n, stride, scale, out):
         out[0] = inp.reshape(-1)[:n * stride:stride].sum() * scale
 

@@ -201,6 +201,16 @@ class OracleTrainer:
             self.G_opt.step(self.PG, grads)
         return {"g_loss": g_loss.item(), "content_loss": cl.item(), "g_c_fake_mean": torch.mean(c_fake).item()}, grads
 
+    @torch.no_grad()
+    def metrics(self, coarse, fine):
+        """mlflow_tools/mlflow_epoch.py:53-63 restricted to the metrics whose arithmetic is in the reference itself:
+        MAE (losses.py:51-53), MSE (losses.py:68-69), Wass (losses.py:8-9).  MS-SSIM goes through the unpinned
+        third-party pytorch_msssim and is not restated."""
+        fake = self.G(coarse)
+        creal = torch.mean(self.C(fine))
+        cfake = torch.mean(self.C(fake))
+        return {"MAE": F.l1_loss(fine, fake).item(), "MSE": F.mse_loss(fine, fake).item(), "Wass": (creal - cfake).item()}
+
     def train_step(self, coarse, fine, alpha):
         """Loop body of _train_epoch, GAN/wasserstein.py:131-147 (metrics pass :140 excluded)."""
         out, _ = self.critic_iteration(coarse, fine, alpha)

@@ -95,6 +95,14 @@ def run_config(name, B, S, F_, cin, nrb, steps, config, hp, W, Generator, Critic
     with torch.no_grad():
         out["forward"]["G_coarse"] = _tensor_summary(G(coarse))
         out["forward"]["C_fine"] = {"values": [float(v) for v in C(fine).flatten()]}
+        # the metrics of the per-step metrics pass whose arithmetic lives in the reference (mlflow_epoch.py:53-63):
+        # the reference's own loss functions applied to the reference networks' outputs
+        import DoWnGAN.GAN.losses as L
+        fake0 = G(coarse)
+        out["forward"]["metrics"] = {
+            "MAE": float(L.content_loss(fine, fake0, config.device)),
+            "MSE": float(L.content_MSELoss(fine, fake0, config.device)),
+            "Wass": float(L.wass_loss(torch.mean(C(fine)), torch.mean(C(fake0)), config.device))}
 
     c_outs = []
     C.register_forward_hook(lambda m, i, o: c_outs.append(o.detach().clone()))

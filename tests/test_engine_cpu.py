@@ -106,6 +106,15 @@ def test_steps_match_reference_golden_cfg1():
         assert rel(float(sd[k].double().norm()), s["l2"]) < 1e-5, k
 
 
+def test_metrics_pass_matches_reference_golden():
+    with open(os.path.join(GOLD, "cin6_small.json")) as f:
+        gold = json.load(f)
+    eng, orc, tc, tf, xc, xf = make(2, 16, 16, 6, 2)
+    m = eng.metrics_pass(xc, xf)
+    for k, v in gold["forward"]["metrics"].items():
+        assert abs(m[k] - v) <= 1e-5 * max(abs(v), 1.0) + 2e-7, (k, m[k], v)
+
+
 def test_state_dict_roundtrip():
     eng, orc, *_ = make(2, 16, 16, 6, 1)
     pg = synthetic.generator_params(16, 6, 2, 1)

@@ -54,6 +54,9 @@ def test_oracle_matches_reference_golden(name, nsteps):
         c = tr.C(fine).flatten().tolist()
     for a, b in zip(c, gold["forward"]["C_fine"]["values"]):
         assert close(a, b, 1e-5, 1e-7)
+    m = tr.metrics(coarse, fine)        # metrics pass before any update (mlflow_epoch.py:53-63)
+    for k, v in gold["forward"]["metrics"].items():
+        assert close(m[k], v, 2e-5, 2e-7), (k, m[k], v)
     for step in range(nsteps):
         rec = gold["steps"][step]
         alpha = torch.from_numpy(synthetic.alpha(B, step))

@@ -66,6 +66,18 @@ def test_fp32_steps_match_reference_golden(name, nsteps):
             assert rel(float(sd[k].double().norm()), s["l2"]) < 5e-5, k
 
 
+@pytest.mark.parametrize("name", ["cfg1", "f32_s32"])
+def test_metrics_pass_matches_reference_golden(name):
+    """MAE / MSE / Wasserstein estimate of the per-step metrics pass (mlflow_epoch.py:53-63) in fp32-parity mode."""
+    with open(os.path.join(GOLD, name + ".json")) as f:
+        gold = json.load(f)
+    c = gold["config"]
+    eng, *_, xc, xf = make(c["B"], c["S"], c["F"], c["cin"], c["num_res_blocks"], "f32")
+    m = eng.metrics_pass(xc, xf)
+    for k, v in gold["forward"]["metrics"].items():
+        assert abs(m[k] - v) <= 1e-4 * max(abs(v), abs(gold["steps"][0]["c_real_mean"])), (k, m[k], v)
+
+
 def test_fp32_gradients_match_float64_oracle():
     B, S, F_, cin, nrb = 2, 16, 16, 6, 2
     eng, pg, pc, tc, tf, xc, xf = make(B, S, F_, cin, nrb, "f32")
