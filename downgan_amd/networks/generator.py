@@ -67,3 +67,18 @@ class Generator:
         return out
 
     __call__ = forward
+
+    def generate(self, coarse, chunk_size=None):
+        """Chunked inference over a long series of coarse fields, like the reference's generation script
+        (reference DoWnGAN/helpers/gen_fake_ds.py:147-162: ``G(chunk)`` per chunk, concatenated on the host)."""
+        n = coarse.shape[0]
+        chunk_size = chunk_size or n
+        outs = []
+        for i in range(0, n, chunk_size):
+            part = coarse[i:i + chunk_size]
+            if part.shape[0] < chunk_size and i > 0:      # pad the ragged tail so one native instance serves all chunks
+                pad = torch.zeros(chunk_size - part.shape[0], *part.shape[1:], dtype=part.dtype, device=part.device)
+                outs.append(self.forward(torch.cat([part, pad], 0))[:part.shape[0]].cpu())
+            else:
+                outs.append(self.forward(part).cpu())
+        return torch.cat(outs, 0)

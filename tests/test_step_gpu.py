@@ -141,6 +141,10 @@ def test_forward_drop_in_modules():
     assert torch.allclose(out_g.cpu(), ref_g, atol=2e-5) and torch.allclose(out_c.cpu(), ref_c, atol=1e-6)
     sd = G.state_dict()
     assert all(torch.equal(sd[k], v) for k, v in pg.items())
+    # chunked generation (gen_fake_ds.py:147-162) incl. a ragged tail == one-shot forward
+    series = torch.from_numpy(synthetic.tiles(5, cin, S, seed=77)[0])
+    whole = G(series.cuda()).cpu()
+    assert torch.allclose(G.generate(series, chunk_size=2), whole, atol=1e-6)
 
 
 def test_full_tile_fp32_parity_cfg2_shapes():
