@@ -327,7 +327,13 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   a.nci_t = (a.Cin + bci - 1) / bci;
   const int ntiles = nco_t * 9 * a.nci_t;
   static const int target_blocks = getenv("DG_WG_BLOCKS") ? atoi(getenv("DG_WG_BLOCKS")) : 2304;   // 3 resident workgroups x 256 CUs x 3 rounds
-  int splits = (target_blocks + ntiles - 1) / ntiles;
+  // every workgroup ends with a 64-KB (tile) atomic accumulate at ~1.3 TB/s chip-wide: cap the workgroup count so
+  // that this traffic stays below ~1/4 of the MFMA time (estimated at 600 TFLOP/s), but keep >= 512 workgroups
+  const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
+  long long cap = (long long)(flops * 5.4e-4 / (bco * bci * 4.0));
+  if (cap < 512) cap = 512;
+  const int tb = target_blocks < cap ? target_blocks : (int)cap;
+  int splits = (tb + ntiles - 1) / ntiles;
   const int max_splits = (a.Mpix + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
