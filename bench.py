@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graphs", action="store_true", help="replay the iterations as captured HIP graphs (small, launch-bound tiles)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gradient exchange goes over gloo")
     args = ap.parse_args()
@@ -141,6 +142,9 @@ def main():
     nsteps = args.warmup + args.steps
     alphas = [torch.from_numpy(synthetic.alpha(B, s, rank=rank)).cuda() for s in range(nsteps)]
 
+    if args.graphs:
+        eng.enable_graphs(xc, xf)
+        args.no_kernel_timing = True          # per-launch events cannot be recorded inside a replayed graph
     for s in range(args.warmup):
         eng.train_step(xc, xf, alphas[s])
     if dist:

@@ -584,12 +584,50 @@ class TrainEngine:
         n = self.n_real_elems * self.world
         return {"MAE": d["l1_sum"] / n, "MSE": d["sq_sum"] / n, "Wass": d["c_real_mean"] - d["c_fake_mean"], "MSSSIM": None}
 
+    # ---- HIP graphs: the ~500 launches of an iteration are captured once and replayed (launch-bound small tiles)
+    def enable_graphs(self, coarse, fine):
+        """Capture the critic and generator iterations (everything up to, not including, the all-reduce + Adam, whose
+        bias correction depends on the host step count) into two HIP graphs.  ``coarse`` / ``fine`` give the shapes;
+        later steps copy their inputs into the captured static buffers.  The reference's small native problem size
+        (2ch 16x16 -> 128x128, hyperparams.py:18 / config.py:112) is launch-bound without this."""
+        o = self.ops
+        assert o.prof is None, "kernel timing hooks record events; disable them before capturing"
+        self._g_coarse, self._g_fine = coarse.clone(), fine.clone()
+        side = torch.cuda.Stream(device=o.device)
+        side.wait_stream(torch.cuda.current_stream(o.device))
+        with torch.cuda.stream(side):                       # eager warm-up: lazy workspaces, function attributes
+            self.critic_iteration(self._g_coarse, self._g_fine, self.alpha_dev, apply_update=False)
+            self.generator_iteration(self._g_coarse, self._g_fine, apply_update=False)
+        torch.cuda.current_stream(o.device).wait_stream(side)
+        torch.cuda.synchronize(o.device)
+        self._graph_c, self._graph_g = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_c):
+            self.critic_iteration(self._g_coarse, self._g_fine, self.alpha_dev, apply_update=False)
+        with torch.cuda.graph(self._graph_g):
+            self.generator_iteration(self._g_coarse, self._g_fine, apply_update=False)
+        self.C.P.zero_grad(); self.G.P.zero_grad()
+        self.graphs = True
+
+    graphs = False
+
     def train_step(self, coarse, fine, alpha):
         """loop body of _train_epoch, wasserstein.py:131-147 (metrics pass :140 excluded)."""
-        self.critic_iteration(coarse, fine, alpha)
         ran_g = self.num_steps % self.hp.critic_iterations == 0   # :136
-        if ran_g:
-            self.generator_iteration(coarse, fine)
+        if self.graphs:
+            if coarse is not self._g_coarse:
+                self._g_coarse.copy_(coarse)
+            if fine is not self._g_fine:
+                self._g_fine.copy_(fine)
+            self.alpha_dev.copy_(alpha)
+            self._graph_c.replay()
+            self._allreduce_and_step(self.C.P)
+            if ran_g:
+                self._graph_g.replay()
+                self._allreduce_and_step(self.G.P)
+        else:
+            self.critic_iteration(coarse, fine, alpha)
+            if ran_g:
+                self.generator_iteration(coarse, fine)
         self.num_steps += 1
         return ran_g
 

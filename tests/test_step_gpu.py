@@ -198,3 +198,22 @@ def test_bf16_drift_at_full_tile_vs_fp32_native():
     print("fp32:", [{k: round(v, 5) for k, v in r.items() if k in ("critic_loss", "gp_ret", "c_real_mean", "c_fake_mean")} for r in res["f32"]])
     assert max(v for k, v in drift.items() if k.startswith("0:")) < 2e-2          # before any update: pure kernel rounding
     assert all(v < 0.25 for v in drift.values())
+
+
+def test_hip_graph_replay_equals_eager():
+    """critic / generator iterations captured into HIP graphs reproduce the eager launches (cfg1, 6 steps, fp32:
+    only the order of the fp32 atomic accumulations differs between the two runs)."""
+    res = {}
+    for graphs in (False, True):
+        eng, *_, xc, xf = make(4, 16, 16, 2, 16, "f32")
+        if graphs:
+            eng.enable_graphs(xc, xf)
+        out = []
+        for step in range(6):
+            alpha = torch.from_numpy(synthetic.alpha(4, step)).cuda()
+            ran_g = eng.train_step(xc, xf, alpha)
+            out.append(eng.read_scalars(ran_g))
+        res[graphs] = out
+    for a, b in zip(res[False], res[True]):
+        for k in a:
+            assert rel(a[k], b[k]) < 1e-5 or abs(a[k] - b[k]) < 1e-7, (k, a[k], b[k])
