@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
   // (2 column groups x 4 rows x 4 column quads, 8 B each) over all 64 banks.
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
   constexpr int LDU = BCO + PADE, LDX = BCI + PADE;
-  __shared__ __attribute__((aligned(16))) T smem[2 * KP * (LDU + LDX)];
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_dsm[];   // 2 * KP * (LDU + LDX) elements
+  T* const smem = reinterpret_cast<T*>(wg_dsm);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = blockIdx.x;
@@ -314,8 +315,9 @@ static int wg_launch_im2col(WGArgs& a, hipStream_t st) {
   a.ppb = ((a.Mpix + splits - 1) / splits + 31) / 32 * 32;
   splits = (a.Mpix + a.ppb - 1) / a.ppb;
   dim3 grid(nco_t, splits);
-  if (big_co) hipLaunchKernelGGL((wg_kernel<T, 128, 64, true, 32, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wg_kernel<T, 64, 64, true, 32, true>), grid, dim3(256), 0, st, a);
+  constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
+  if (big_co) hipLaunchKernelGGL((wg_kernel<T, 128, 64, true, 32, true>), grid, dim3(256), 2 * 32 * (128 + 64 + 2 * PADE) * (int)sizeof(T), st, a);
+  else hipLaunchKernelGGL((wg_kernel<T, 64, 64, true, 32, true>), grid, dim3(256), 2 * 32 * (64 + 64 + 2 * PADE) * (int)sizeof(T), st, a);
   return dg_check_launch();
 }
 
@@ -342,20 +344,34 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   dim3 grid(ntiles, splits);
   static const bool no_rowstep = getenv("DG_WG_GENERIC") != nullptr;
   const bool rs = !no_rowstep && a.Wo % 32 == 0;
-  // 64-pixel K-steps halve the barrier count; they need Wo % 64 == 0 and 2 x 64 x (BCO+BCI) elements of LDS
-  static const bool no_kp64 = getenv("DG_WG_KP32") != nullptr;
-  const bool kp64 = rs && !no_kp64 && a.Wo % 64 == 0 && a.ppb % 64 == 0 && sizeof(T) == 2 && !(big_co && big_ci);   // padded 128x128 tiles: 64-pixel steps exceed 64 KB of static LDS
+  // 64-pixel K-steps halve the barrier count but also the resident workgroups (LDS): measured equal to 32-pixel
+  // steps, so they are opt-in
+  static const bool want_kp64 = getenv("DG_WG_KP64") != nullptr;
+  const bool kp64 = rs && want_kp64 && a.Wo % 64 == 0 && a.ppb % 64 == 0 && sizeof(T) == 2;
+  constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
+#define WG_LAUNCH1(BCO, BCI, RS, KPV)                                                                 \
+  do {                                                                                                \
+    const int lds = 2 * KPV * (BCO + BCI + 2 * PADE) * (int)sizeof(T);                                \
+    static bool attr = false;                                                                         \
+    if (!attr && lds > 65536) {                                                                       \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wg_kernel<T, BCO, BCI, RS, KPV>),        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DG_ERR_LAUNCH; \
+      attr = true;                                                                                    \
+    }                                                                                                 \
+    hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, RS, KPV>), grid, dim3(256), lds, st, a);               \
+  } while (0)
 #define WG_LAUNCH(BCO, BCI)                                                                           \
   do {                                                                                                \
-    if (kp64) { if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, true, 64>), grid, dim3(256), 0, st, a); } \
-    else if (rs) hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, true, 32>), grid, dim3(256), 0, st, a);   \
-    else hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, false, 32>), grid, dim3(256), 0, st, a);          \
+    if (kp64) { if constexpr (sizeof(T) == 2) WG_LAUNCH1(BCO, BCI, true, 64); }                       \
+    else if (rs) WG_LAUNCH1(BCO, BCI, true, 32);                                                      \
+    else WG_LAUNCH1(BCO, BCI, false, 32);                                                             \
   } while (0)
   if (big_co && big_ci) WG_LAUNCH(128, 128);
   else if (big_co) WG_LAUNCH(128, 64);
   else if (big_ci) WG_LAUNCH(64, 128);
   else WG_LAUNCH(64, 64);
 #undef WG_LAUNCH
+#undef WG_LAUNCH1
   return dg_check_launch();
 }
 
