@@ -410,13 +410,16 @@ __global__ __launch_bounds__(256, 2) void gg_fast_kernel(const GGArgs a) {
   const int l15 = lane & 15, g = lane >> 4;
   const int nk = a.kchunks >> 3;
 
+  // write-after-barrier pipeline: the registers filled during step ks-1 are stored at the START of step ks and
+  // refilled at once with the loads of step ks+2, so a load has a whole step to arrive
   gload();
   lstore(0);
+  if (nk > 1) gload();
   __syncthreads();
   int cur = 0;
   for (int ks = 0; ks < nk; ++ks) {
-    const bool more = ks + 1 < nk;
-    if (more) gload();
+    if (ks + 1 < nk) lstore(cur ^ 1);
+    if (ks + 2 < nk) gload();
     const uint4* s = smem + cur * ROWS * 8;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -437,7 +440,6 @@ __global__ __launch_bounds__(256, 2) void gg_fast_kernel(const GGArgs a) {
 #pragma unroll
         for (int i = 0; i < FP; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
     }
-    if (more) lstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
@@ -818,15 +820,24 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   load_w(0, 0);
   store_patch();
   store_w(0);
+  int cb = 0, tap = 0;
+  int cb2 = 0, tap2 = 0;             // position of the weight tile the registers are being filled with (step s+2)
+  auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps) { t_ = 0; ++c_; } };
+  adv(cb2, tap2);
+  if (nsteps > 1) load_w(cb2, tap2);   // step 1
+  adv(cb2, tap2);
   __syncthreads();
 
   uint4 fa0[4], fb0[4], fa1[4], fb1[4];
-  int cb = 0, tap = 0;
   for (int s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
     int ntap = tap + 1, ncbn = cb;
     if (ntap == ntaps) { ntap = 0; ncbn = cb + 1; }
-    if (more) load_w(ncbn, ntap);
+    // write-after-barrier: weights of step s+1 (fetched during step s-1) go to the other slot now, and the registers
+    // are refilled with step s+2 at once, so each weight load has a whole step to arrive
+    if (more) store_w((s & 1) ^ 1);
+    if (s + 2 < nsteps) load_w(cb2, tap2);
+    adv(cb2, tap2);
     if (tap == 0 && cb + 1 < ncb) load_patch(cb + 1);
     const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
     const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
@@ -847,7 +858,6 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
     __builtin_amdgcn_sched_barrier(0);
     mma_block(fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) store_w(slot ^ 1);
     if (ntap == 0 && more) {          // channel-block boundary: swap the single-buffered patch between two barriers
       __syncthreads();
       store_patch();

@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
   const int nsteps = (pend - pbeg + KP - 1) / KP;
   if (nsteps <= 0) return;
 
+  // store-before-barrier pipeline: loads of step ks+1 are issued before the MFMA phase of step ks and stored after it.
+  // (The write-after-barrier order with a full-step latency budget was measured: +5 % on the compute-bound layers,
+  // -10 % on the 512^2/1024^2 layers, -7 % on the whole step's weight gradients.)
   gload(pbeg);
   lstore(0);
   __syncthreads();
