@@ -50,13 +50,18 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
   T* const smem = reinterpret_cast<T*>(wg_dsm);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bx = blockIdx.x;
+  // XCD-aware remap of the linear workgroup id: the 9 tap-workgroups (and channel tiles) of one pixel range become
+  // consecutive ids on ONE XCD, so the tiles they all re-read are served by that XCD's L2 instead of the fabric
+  // (measured: +15-35 % on layers with <= 72 tiles per pixel range, -5-12 % on the widest layers, hence the gate)
+  const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned lin = gridDim.x <= 72 ? xcd_remap(lin0, gridDim.x * gridDim.y) : lin0;
+  const int bx = (int)(lin % gridDim.x), by = (int)(lin / gridDim.x);
   const int ci_t = IM2COL ? 0 : bx % a.nci_t;
   const int tap = IM2COL ? 4 : (bx / a.nci_t) % 9;
   const int co_t = IM2COL ? bx : bx / (a.nci_t * 9);
   const int co0 = co_t * BCO, ci0 = ci_t * BCI;
   const int dr = tap / 3 - 1, dc = tap % 3 - 1;
-  const int pbeg = blockIdx.y * a.ppb;
+  const int pbeg = by * a.ppb;
   const int pend = min(a.Mpix, pbeg + a.ppb);
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ U = reinterpret_cast<const T*>(a.u);
