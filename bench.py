@@ -101,6 +101,21 @@ def cpu_baseline(args, wl):
     return {"value": 1.0 / ((tc + tg / 5.0) * area), "unit": "samples/s", "cores": cores, "kind": "port", "sample": sample}
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction).  PMC counters cannot be
+    collected from inside the process, so the number is read from profiles/ and is null for any other workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_cfg2_bf16.json")
+    if args.workload != "cfg2" or args.dtype != "bf16" or args.batch or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    for k, v in d["kernels"].items():
+        if k.startswith(kernel):
+            return round(v["traffic_bytes_per_launch"]), "profiles/pmc_traffic_cfg2_bf16.json (" + d["formula"] + ")"
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,10 +185,10 @@ def main():
     kernels = {}
     if ops.prof:
         agg = {}
-        for tag, flops, s_ev, e_ev in ops.prof:
-            a = agg.setdefault(tag, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += s_ev.elapsed_time(e_ev) * 1e-3; a[2] += 1
-        for tag, (fl, sec, n) in agg.items():
+        for tag, flops, nbytes, s_ev, e_ev in ops.prof:
+            a = agg.setdefault(tag, [0.0, 0.0, 0, 0.0])
+            a[0] += flops; a[1] += s_ev.elapsed_time(e_ev) * 1e-3; a[2] += 1; a[3] += nbytes
+        for tag, (fl, sec, n, _nb) in agg.items():
             kernels[tag] = {"launches": n, "seconds": round(sec, 4), "tflops": round(fl / sec / 1e12, 2) if sec > 0 else None}
         # dominant kernel: gg_halo128_kernel (stride-1 conv forward + stride-1 data gradient; gg_halo_kernel is its
         # 64-channel-step sibling for Cred % 128 != 0, not used at cfg2).  Only calls that were
@@ -185,8 +200,11 @@ def main():
         nl = sum(agg[t][2] for t in halo)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         ach = fl / sec / 1e12 if sec > 0 else 0.0
+        alg_bytes = sum(agg[t][3] for t in halo) / max(nl, 1)
+        traffic, traffic_src = pmc_traffic("gg_halo128_kernel", args)
         roofline = {"kernel": "gg_halo128_kernel (implicit-GEMM conv3x3, stride-1 forward + data-gradient)", "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "alg_bytes_per_launch": round(alg_bytes),
                     "launches": nl, "avg_launch_ms": round(sec / max(nl, 1) * 1e3, 4),
                     "share_of_step": round(sec / elapsed, 3)}
         ops.prof = None

@@ -72,13 +72,13 @@ class HipOps:
         self.dg = DG_DTYPE[dtype]
         self.device = torch.device(device)
         self.lib = _lib.lib()
-        self.prof = None      # optional list of (tag, flops, start_event, end_event): bench.py's live kernel timing
+        self.prof = None      # optional list of (tag, flops, bytes, start_event, end_event): bench.py's live kernel timing
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _timed(self, tag, flops, fn):
+    def _timed(self, tag, flops, fn, nbytes=0.0):
         """Run one launch; when profiling is on, bracket it with HIP events on the launch stream."""
         if self.prof is None:
             return fn()
@@ -88,13 +88,21 @@ class HipOps:
         e.record()
         if tag in ("conv_fwd", "conv_dgrad"):
             tag = f"{tag}:k{self.lib.dg_last_conv_kernels()}"   # which kernel variant(s) served the call
-        self.prof.append((tag, flops, s, e))
+        self.prof.append((tag, flops, nbytes, s, e))
         return rc
 
     @staticmethod
     def conv_flops(cv):
         """algorithmic flops of one conv pass: 2*9*Cin*Cout*Ho*Wo per image, padded channels."""
         return 2.0 * 9 * cv.Cin * cv.Cout * cv.Ho * cv.Wo * cv.N
+
+    def conv_bytes(self, cv, ep=None):
+        """algorithmic HBM bytes of one conv pass: input + output + weights once each, plus the output-sized
+        epilogue operands (residuals, activation mask, accumulate) that are passed."""
+        es = 2 if self.dtype == "bf16" else 4
+        out = cv.N * cv.Ho * cv.Wo * cv.Cout
+        extra = 0 if ep is None else sum(1 for k in ("r1", "r2", "mask") if ep.get(k) is not None) + int(bool(ep.get("accumulate")))
+        return float(es * (cv.N * cv.H * cv.W * cv.Cin + out * (1 + extra) + 9 * cv.Cin * cv.Cout))
 
     def _act(self, t):
         assert t.dtype == self.tdtype and t.is_cuda, (t.dtype, t.device)
@@ -142,7 +150,7 @@ class HipOps:
         g = self._geom(cv, pix_layout(x)[0], pix_layout(y)[0])
         e = self._epilogue(y, **ep)
         check(self._timed("conv_fwd", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_fwd(
-            C.byref(g), C.byref(e), _ptr(x), _ptr(w_fwd), _ptr(y), self._stream())), "dg_conv3x3_fwd")
+            C.byref(g), C.byref(e), _ptr(x), _ptr(w_fwd), _ptr(y), self._stream()), self.conv_bytes(cv, ep)), "dg_conv3x3_fwd")
 
     def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, **ep):
         self._act(dy); self._act(dx); self._act(w_dgrad)
@@ -152,7 +160,7 @@ class HipOps:
         g = self._geom(cv, pix_layout(dx)[0], pix_layout(dy)[0])
         e = self._epilogue(dx, **ep)
         check(self._timed("conv_dgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_dgrad(
-            C.byref(g), C.byref(e), _ptr(dy), _ptr(w_dgrad), _ptr(dx), self._stream())), "dg_conv3x3_dgrad")
+            C.byref(g), C.byref(e), _ptr(dy), _ptr(w_dgrad), _ptr(dx), self._stream()), self.conv_bytes(cv, ep)), "dg_conv3x3_dgrad")
 
     def conv_wgrad(self, cv: Conv, x, dy, dw, db=None):
         """dw += weight gradient; db (optional, fp32 [Cout]) += bias gradient = column sums of dy."""
@@ -163,7 +171,7 @@ class HipOps:
         assert tuple(dy.shape) == self.out_shape(cv), (dy.shape, cv)
         g = self._geom(cv, pix_layout(x)[0], pix_layout(dy)[0])
         check(self._timed("conv_wgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad(
-            C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), self._stream())), "dg_conv3x3_wgrad")
+            C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), self._stream()), self.conv_bytes(cv)), "dg_conv3x3_wgrad")
 
     def colsum(self, dy, db):
         """db[c] += sum over all pixels/rows of dy[..., c]; dy is NHWC (any dtype of {fp32, compute}) or 2-D."""
