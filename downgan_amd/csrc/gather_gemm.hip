@@ -646,6 +646,10 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
       fb[i] = sp[pr * 8 + (ch ^ ((pr >> 1) & 7))];
     }
   };
+  auto mma_row = [&](const uint4 (&fa)[4], const uint4 (&fb)[4], int j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
+  };
   auto mma_block = [&](const uint4 (&fa)[4], const uint4 (&fb)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -714,6 +718,18 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
 // the two waves of a SIMD + scalar bookkeeping), against 1024 MFMA-pipe cycles: doubling the channels per step
 // doubles the MFMA work those fixed costs are amortised over.  The patch is single-buffered (83 KB) and swapped
 // at the channel-block boundary between two barriers; weights use two 32-KB slots with a register prefetch.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+#ifdef DG_STAMP
+// diagnostic build only (make stamp): per-wave cycle sums of the segments of a tap-step, blocks 0/1
+__device__ unsigned long long g_stamps[2 * 8 * 8];
+extern "C" int dg_debug_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
+}
+#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(v) do { } while (0)
+#endif
 template <typename T>
 __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int tiles_x, int tiles_y) {
   constexpr int EPC = DT<T>::EPC;
@@ -722,9 +738,15 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   constexpr int BC = 128, KC = 16;                                       // 16 chunks per row
   constexpr int NPL = (PROWS * KC + 511) / 512;                          // 11 patch chunks per thread
   constexpr int NWL = BC * KC / 512;                                     // 4 weight chunks per thread
-  extern __shared__ __attribute__((aligned(16))) uint4 dsm[];
-  uint4* const s_patch = dsm;                    // [PROWS][16]
-  uint4* const s_w = dsm + PROWS * KC;           // [2][BC][16]
+  // LDS rows are 256 B of data + 16 B of padding: 16 consecutive rows then start 4 banks apart, so a fragment read
+  // (16 lanes = 16 consecutive rows at one chunk) is conflict-free at ANY row offset without an XOR swizzle, and every
+  // per-k-chunk / per-row address is base + immediate (no per-read VALU address arithmetic).
+  constexpr int PITCH = KC * 16 + 16;            // 272 bytes
+  extern __shared__ __attribute__((aligned(16))) char dsm128[];
+  char* const s_patch = dsm128;                  // [PROWS][PITCH]
+  // weights: [2][BC][256 B], no padding (written by LDS-DMA, which fills 1 KB contiguously per wave-instruction); the
+  // 16-byte chunk c of row r sits at chunk position c ^ (r & 15) -- conflict-free for the 16-row-aligned fragment reads
+  char* const s_w = dsm128 + PROWS * PITCH;      // [2][BC][KC * 16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
@@ -737,51 +759,75 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   const int cc = tid & 15, r0 = tid >> 4;        // r0 in [0,32)
 
   const int sy_base = ty0 - 1 > 0 ? ty0 - 1 : 0;
-  unsigned poff[NPL];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int pr = r0 + 32 * i;
-    const int py = pr / PW, px = pr - py * PW;
-    const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
-    const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-    poff[i] = ok ? (unsigned)(((long long)(sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
-  }
-  unsigned woff[NWL];
+  unsigned woff[NWL];                            // lane's source offset for DMA piece i: row r0+32i, chunk cc ^ (r0 & 15)
 #pragma unroll
   for (int i = 0; i < NWL; ++i) {
-    const int row = r0 + 32 * i;
-    woff[i] = (c0 + row < a.Nout) ? (unsigned)((long long)row * a.ldw * ES) + cc * 16 : DG_OOB_OFF;
+    int row = r0 + 32 * i;
+    if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;   // rows past Cout: any valid row (their outputs are never stored)
+    woff[i] = (unsigned)((long long)row * a.ldw * ES) + ((cc ^ (r0 & 15)) * 16);
   }
   const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
   const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
 
-  u32x4_t rp[NPL], rw[NWL];
+  u32x4_t rp[NPL];
   auto load_patch = [&](int cb) {
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+    // offsets are recomputed per channel block (once per ntaps steps) instead of living in 11 registers; the empty
+    // asm keeps the compiler from hoisting them back out of the step loop
+    int r0v = r0;
+    asm volatile("" : "+v"(r0v));
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, poff[i], 0, 0);
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0v + 32 * i;
+      const int py = pr / PW, px = pr - py * PW;
+      const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+      const unsigned off = ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
+      rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);      // one offset live at a time: the kernel sits at the 256-VGPR limit
+    }
   };
+  char* const st_base = dsm128 + r0 * PITCH + cc * 16;
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       const int pr = r0 + 32 * i;
-      if (pr < PROWS) s_patch[pr * KC + (cc ^ (pr & 15))] = __builtin_bit_cast(uint4, rp[i]);
+      if (pr < PROWS) *reinterpret_cast<uint4*>(st_base + i * 32 * PITCH) = __builtin_bit_cast(uint4, rp[i]);
     }
   };
-  auto load_w = [&](int cb, int tap) {
+  // LDS-DMA of one 128x128 weight tile: 4 pieces of 1 KB per wave.  Issued as inline asm: for the builtin the compiler
+  // assumes the DMA may alias every later LDS read and drains vmcnt(0) in front of the fragment prefetch, which serialises
+  // the fetch with the MFMA blocks it should hide under.  (Its own vmcnt bookkeeping stays safe: unknown extra loads only
+  // make counted waits stricter.)  m0 is not otherwise used by this kernel.
+  i32x4_t w_rs;
+  int w_dst0 = 0;
+  auto dma_setup = [&](int cb, int tap, int slot) {
     const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
     const long long wo = (long long)(code >> 4) * a.Cred + cb * KC * EPC;
-    __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + wo * ES), 0, (int)DG_OOB_OFF, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rwd, woff[i], 0, 0);
+    const unsigned long long wbase = (unsigned long long)(Wb + wo * ES);
+    w_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wbase);
+    w_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(wbase >> 32) & 0xffff);
+    w_rs[2] = (int)DG_OOB_OFF;
+    w_rs[3] = 0x00020000;
+    w_dst0 = __builtin_amdgcn_readfirstlane(
+        (int)(unsigned long long)((__attribute__((address_space(3))) char*)(s_w + slot * (BC * KC * 16) + (wave * 4) * (KC * 16))));
   };
-  auto store_w = [&](int slot) {
-    uint4* s = s_w + slot * BC * KC;
+  auto dma_piece = [&](int i) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(w_dst0 + i * 32 * KC * 16), "v"(woff[i]), "s"(w_rs) : "memory");
+  };
+  auto dma_w = [&](int cb, int tap, int slot) {
+    dma_setup(cb, tap, slot);
 #pragma unroll
-    for (int i = 0; i < NWL; ++i) {
-      const int row = r0 + 32 * i;
-      s[row * KC + (cc ^ (row & 15))] = __builtin_bit_cast(uint4, rw[i]);
-    }
+    for (int i = 0; i < NWL; ++i) dma_piece(i);
+  };
+  auto barrier_all = [&]() {        // LDS-DMA is tracked by vmcnt: drain it before the barrier publishes the tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  auto barrier_keep_patch = [&]() { // the 11 patch loads issued after the DMA pieces may stay in flight
+    asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    __syncthreads();
   };
 
   f32x4_t acc[4][4];
@@ -795,19 +841,19 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   const int ncb = a.cch / KC, ntaps = a.ntaps;
   const int nsteps = ncb * ntaps;
 
-  auto read_frags = [&](uint4 (&fa)[4], uint4 (&fb)[4], int prow0, int slot, int kk) {
-    const uint4* sw = s_w + slot * BC * KC;
-    const int ch = kk * 4 + g;
+  const char* fa_k[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = wc * 64 + 16 * j + l15;
-      fa[j] = sw[row * KC + (ch ^ (row & 15))];
-    }
+  for (int kk = 0; kk < 4; ++kk) fa_k[kk] = s_w + (wc * 64 + l15) * (KC * 16) + (((kk * 4 + g) ^ l15) * 16);
+  const char* const fb_lane = s_patch + l15 * PITCH + g * 16;
+  auto read_frags = [&](uint4 (&fa)[4], uint4 (&fb)[4], int pa, const char* pb, int kk) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pr = prow0 + i * PW;
-      fb[i] = s_patch[pr * KC + (ch ^ (pr & 15))];
-    }
+    for (int j = 0; j < 4; ++j) fa[j] = *reinterpret_cast<const uint4*>(fa_k[kk] + pa + j * 16 * KC * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + kk * 64);
+  };
+  auto mma_row = [&](const uint4 (&fa)[4], const uint4 (&fb)[4], int j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
   };
   auto mma_block = [&](const uint4 (&fa)[4], const uint4 (&fb)[4]) {
 #pragma unroll
@@ -816,62 +862,107 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
       for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
   };
 
-  load_patch(0);
-  load_w(0, 0);
-  store_patch();
-  store_w(0);
-  int cb = 0, tap = 0;
-  int cb2 = 0, tap2 = 0;             // position of the weight tile the registers are being filled with (step s+2)
+  // Schedule: ONE barrier per tap-step, in the MIDDLE of the step.  A step's 64 MFMAs per wave are four blocks of 16
+  // (k-chunks 0..3).  Fragments of blocks 0/1 are prefetched at the end of the previous step, so MFMAs are ready to issue
+  // on both sides of the barrier (in-kernel stamps of the barrier-at-step-end version: ~1000 cycles without MFMAs after
+  // each barrier while 8 waves queue LDS stores + 16 fragment reads, and the two waves of a SIMD ran one after the other).
+  //   step s:  mma(blk0) | read blk2 | mma(blk1) | read blk3 | BARRIER (all reads of weight slot s&1 done)
+  //            LDS-DMA W[s+2] -> slot s&1 | mma(blk2) | read blk0 of step s+1 | mma(blk3) | read blk1 of s+1
+  // W[s+1] was DMA'd into slot (s+1)&1 after the barrier of step s-1 and published by the barrier of step s.  At a channel-block boundary the single-buffered patch is
+  // rewritten after the barrier (every wave holds its last fragments in registers) and a second barrier publishes it.
   auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps) { t_ = 0; ++c_; } };
-  adv(cb2, tap2);
-  if (nsteps > 1) load_w(cb2, tap2);   // step 1
-  adv(cb2, tap2);
-  __syncthreads();
+  auto patch_ptr = [&](int tap_) -> const char* {
+    const unsigned code = tap_ < 8 ? (unsigned)((a.tap_lo >> (8 * tap_)) & 0xffull) : (a.tap_hi & 0xffu);
+    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
+    return fb_lane + ((wp * 4 + 1 + dy) * PW + 1 + dx) * PITCH;
+  };
+  load_patch(0);
+  int cb = 0, tap = 0;
+  int cbw = 0, tapw = 0;             // position of the next weight tile to fetch
+  dma_w(0, 0, 0);
+  adv(cbw, tapw);
+  if (nsteps > 1) dma_w(cbw, tapw, 1);
+  adv(cbw, tapw);                    // -> W[2]
+  store_patch();
+  barrier_all();
 
   uint4 fa0[4], fb0[4], fa1[4], fb1[4];
+  const char* pb = patch_ptr(0);
+  int pa = 0;                        // byte offset of the weight slot being read
+  read_frags(fa0, fb0, pa, pb, 0);
+  read_frags(fa1, fb1, pa, pb, 1);
+#ifdef DG_STAMP
+  unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, sAB = 0, sBC = 0, sCD = 0, sDE = 0, tL0 = 0;
+  STAMP(tL0);
+#endif
   for (int s = 0; s < nsteps; ++s) {
+    STAMP(tA);
     const bool more = s + 1 < nsteps;
     int ntap = tap + 1, ncbn = cb;
     if (ntap == ntaps) { ntap = 0; ncbn = cb + 1; }
-    // write-after-barrier: weights of step s+1 (fetched during step s-1) go to the other slot now, and the registers
-    // are refilled with step s+2 at once, so each weight load has a whole step to arrive
-    if (more) store_w((s & 1) ^ 1);
-    if (s + 2 < nsteps) load_w(cb2, tap2);
-    adv(cb2, tap2);
-    if (tap == 0 && cb + 1 < ncb) load_patch(cb + 1);
-    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
-    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
-    const int prow0 = (wp * 4 + 1 + dy) * PW + 1 + dx + l15;
-    const int slot = s & 1;
-    read_frags(fa0, fb0, prow0, slot, 0);
-    read_frags(fa1, fb1, prow0, slot, 1);
+    const bool swap = ntap == 0 && more;
     __builtin_amdgcn_sched_barrier(0);
     mma_block(fa0, fb0);
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(fa0, fb0, prow0, slot, 2);
+    read_frags(fa0, fb0, pa, pb, 2);
     __builtin_amdgcn_sched_barrier(0);
     mma_block(fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(fa1, fb1, prow0, slot, 3);
+    read_frags(fa1, fb1, pa, pb, 3);
     __builtin_amdgcn_sched_barrier(0);
-    mma_block(fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_block(fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ntap == 0 && more) {          // channel-block boundary: swap the single-buffered patch between two barriers
-      __syncthreads();
-      store_patch();
+    STAMP(tB);
+    if (tap == 1 && cb + 1 < ncb) barrier_keep_patch(); else barrier_all();
+    STAMP(tC);
+    const bool fetch = s + 2 < nsteps;
+    if (fetch) dma_setup(cbw, tapw, s & 1);
+    adv(cbw, tapw);
+    pa = ((s + 1) & 1) * (BC * KC * 16);
+    pb = patch_ptr(ntap);
+    if (swap) store_patch();
+    // the MFMA blocks stay in straight-line code (no accumulator phis): only the small side operations are conditional.
+    // One DMA piece goes behind each row of MFMAs, so its issue cost hides in the gaps between this wave's MFMAs.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
+      mma_row(fa0, fb0, j);
+      __builtin_amdgcn_sched_barrier(0);
+      if (fetch) dma_piece(j);
     }
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap == 0 && cb + 1 < ncb) load_patch(cb + 1);   // a whole channel block ahead; kept out of the next vmcnt wait
+    __builtin_amdgcn_sched_barrier(0);
+    if (swap) barrier_all();                 // publish the new patch before the next step's fragments are read
+    read_frags(fa0, fb0, pa, pb, 0);         // (after the last step: a harmless read of valid LDS)
+    __builtin_amdgcn_sched_barrier(0);
+    mma_block(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(fa1, fb1, pa, pb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(tD);
+#ifdef DG_STAMP
+    tE = tD;
+    sAB += tB - tA; sBC += tC - tB; sCD += tD - tC; sDE += tE - tD;
+#endif
     tap = ntap; cb = ncbn;
   }
+#ifdef DG_STAMP
+  unsigned long long tL1, tX;
+  STAMP(tL1);
+#endif
 
   halo_epilogue<T>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
+#ifdef DG_STAMP
+  STAMP(tX);
+  if (blockIdx.x < 2 && lane == 0) {
+    unsigned long long* o = g_stamps + (blockIdx.x * 8 + wave) * 8;
+    o[0] = sAB; o[1] = sBC; o[2] = sCD; o[3] = sDE; o[4] = (unsigned long long)nsteps; o[5] = tL1 - tL0; o[6] = tX - tL1; o[7] = tL0;
+  }
+#endif
 }
 
 template <typename T>
 static int gg_launch_halo128(GGArgs& a, int N, hipStream_t st) {
-  constexpr int LDS_BYTES = (324 + 2 * 128) * 16 * 16;
+  constexpr int LDS_BYTES = 324 * 272 + 2 * 128 * 256;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)

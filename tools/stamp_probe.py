@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-segment cycle sums of the halo kernel's tap-step (needs the -DDG_STAMP build of gather_gemm)."""
+"""Diagnostic: per-segment cycle sums of the halo kernel's tap-step.
+
+    make -C downgan_amd/csrc stamp && DG_LIB_OVERRIDE=downgan_amd/csrc/libdowngan_hip_stamp.so python tools/stamp_probe.py
+"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,5 +27,5 @@ for name, N, H, ci, co in [("G.b5 640->128@128", 16, 128, 640, 128), ("C.l6 512-
         for wv in range(8):
             v = [buf[(b * 8 + wv) * 8 + k] for k in range(8)]
             n = max(v[4], 1)
-            print(f"  blk {b} wave {wv}: steps {v[4]:3d}  per-step cycles: A->B {v[0]/n:7.0f}  B->C {v[1]/n:7.0f}  C->D(store) {v[2]/n:6.0f}  D->E(barrier) {v[3]/n:6.0f}"
+            print(f"  blk {b} wave {wv}: steps {v[4]:3d}  per-step cycles: first half (mma0,1 issued + reads 2,3 issued) {v[0]/n:7.0f}  barrier {v[1]/n:7.0f}  second half {v[2]/n:6.0f}"
                   f"  sum {sum(v[:4])/n:7.0f} | loop {v[5]:8d}  epilogue {v[6]:7d}")
