@@ -950,6 +950,8 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   STAMP(tL1);
 #endif
 
+  // (an LDS-staged epilogue with 16-byte row stores measured 0.8 % slower end to end: the tail is bound by the
+  // chip-wide write burst, and the staging adds two barriers)
   halo_epilogue<T>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
 #ifdef DG_STAMP
   STAMP(tX);
