@@ -85,7 +85,7 @@ class WassersteinGAN:
 
     def gen_batch_and_log_metrics(self, coarse, fine):
         """Native version of mlflow_tools/mlflow_epoch.py:53-63 (the per-step metrics pass, wasserstein.py:140):
-        returns {"MAE", "MSE", "Wass", "MSSSIM": None}."""
+        returns {"MAE", "MSE", "Wass", "MSSSIM"} (MSSSIM None for tiles too small for 5 scales)."""
         e = self._eng(coarse, fine)
         xc, xf = self._to_native(e, coarse, fine)
         return e.metrics_pass(xc, xf)

@@ -40,6 +40,15 @@ class GGDesc(C.Structure):
                 ("dst_ps", C.c_int)]
 
 
+class SsimParams(C.Structure):
+    _fields_ = [("win", C.c_int), ("g", C.c_float * 11), ("C1", C.c_float), ("C2", C.c_float)]
+
+
+class MsssimCombine(C.Structure):
+    _fields_ = [("inv_count", C.c_float * 5), ("weight", C.c_float * 5)]
+
+
+MINMAX_PARTS = 256
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
     "dg_conv3x3_fwd": [C.POINTER(ConvGeom), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
@@ -68,6 +77,12 @@ _PROTOS = {
     "dg_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "dg_nhwc_to_nchw": [_i, _vp, _i64, _vp, _i, _i, _i, _i, _vp],
     "dg_cast": [_i, _vp, _vp, _i64, _vp],
+    "dg_minmax_partial": [_i, _vp, _i64, _i64, _i, _vp, _vp],
+    "dg_minmax_finish": [_vp, _i, _vp, _vp],
+    "dg_normalise_planar": [_i, _vp, _i, _i, _i, _i64, _i, _vp, _vp, _vp],
+    "dg_ssim_level": [_vp, _vp, _i, _i, _i, C.POINTER(SsimParams), _vp, _vp],
+    "dg_avgpool2": [_vp, _vp, _i, _i, _i, _vp],
+    "dg_msssim_finish": [_vp, _i, _i, C.POINTER(MsssimCombine), _vp, _vp],
 }
 EXPORTS = ["dg_version"] + list(_PROTOS)
 

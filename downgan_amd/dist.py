@@ -54,6 +54,19 @@ class Dist:
             out[k] = v / self.world_size if k in mean else v
         return out
 
+    def minmax_(self, mm, c):
+        """In-place global min / max of a [rows, 2*c] tensor laid out (min_0, max_0, min_1, max_1, ...) per row: the
+        batch-wide channel extrema of the MS-SSIM normalisation (losses.py:15-29) when the batch is sharded over ranks."""
+        if self.world_size == 1:
+            return
+        t = mm.view(-1, c, 2)
+        t = t if self.backend == "nccl" else t.cpu()
+        lo, hi = t[..., 0].contiguous(), t[..., 1].contiguous()
+        td.all_reduce(lo, op=td.ReduceOp.MIN)
+        td.all_reduce(hi, op=td.ReduceOp.MAX)
+        mm.view(-1, c, 2)[..., 0].copy_(lo)
+        mm.view(-1, c, 2)[..., 1].copy_(hi)
+
     def barrier(self):
         if self.world_size > 1:
             td.barrier()

@@ -566,7 +566,8 @@ class TrainEngine:
     def metrics_pass(self, coarse, fine):
         """Per-batch evaluation metrics of the reference's training loop (mlflow_tools/mlflow_epoch.py:53-63 called at
         wasserstein.py:140): MAE = L1(real, G(x)) (losses.py:40-55), MSE (losses.py:58-70), Wass = mean C(real) -
-        mean C(G(x)) (losses.py:8-9).  MS-SSIM (losses.py:12-38, third-party pytorch_msssim) is not computed natively."""
+        mean C(G(x)) (losses.py:8-9), MSSSIM = MS-SSIM of the batch-min-max-normalised fields (losses.py:12-38; msssim.py).
+        MSSSIM is None when the tile is too small for 5 scales (pytorch_msssim asserts side > 96)."""
         o, C, B = self.ops, self.C, self.B
         fake = self.G.forward(coarse, save=False)
         m = self.scal[5:8]
@@ -582,7 +583,16 @@ class TrainEngine:
         if self.dist is not None and self.world > 1:
             d = self.dist.reduce_scalars(d, mean=("c_real_mean", "c_fake_mean"), total=("l1_sum", "sq_sum"))
         n = self.n_real_elems * self.world
-        return {"MAE": d["l1_sum"] / n, "MSE": d["sq_sum"] / n, "Wass": d["c_real_mean"] - d["c_fake_mean"], "MSSSIM": None}
+        msssim = None
+        H, W = fine.shape[1], fine.shape[2]
+        if min(H, W) > 96:
+            if self._msssim is None:
+                from .msssim import MsSsim
+                self._msssim = MsSsim(o, B, H, W, c_real=self.G.npred)
+            msssim = self._msssim(fine, fake, dist=self.dist, world=self.world)
+        return {"MAE": d["l1_sum"] / n, "MSE": d["sq_sum"] / n, "Wass": d["c_real_mean"] - d["c_fake_mean"], "MSSSIM": msssim}
+
+    _msssim = None
 
     # ---- HIP graphs: the ~500 launches of an iteration are captured once and replayed (launch-bound small tiles)
     def enable_graphs(self, coarse, fine):

@@ -290,6 +290,38 @@ class HipOps:
         lda, rows = pix_layout(a)
         check(self.lib.dg_sqdiff(self.dg, _ptr(a), lda, _ptr(b), pix_layout(b)[0], rows, a.shape[-1], _ptr(acc), self._stream()), "dg_sqdiff")
 
+    # ------------------------------------------------------------------ MS-SSIM pieces (metrics pass)
+    def minmax(self, x, c_real, partial, minmax):
+        """minmax[c] = (min, max) of channel c < c_real over every pixel of the NHWC tensor x."""
+        self._act(x)
+        assert partial.dtype == torch.float32 and partial.numel() >= _lib.MINMAX_PARTS * c_real * 2 and minmax.numel() >= 2 * c_real
+        ld, rows = pix_layout(x)
+        check(self.lib.dg_minmax_partial(self.dg, _ptr(x), rows, ld, c_real, _ptr(partial), self._stream()), "dg_minmax_partial")
+        check(self.lib.dg_minmax_finish(_ptr(partial), c_real, _ptr(minmax), self._stream()), "dg_minmax_finish")
+
+    def normalise_planar(self, x, c_real, minmax, out):
+        """out[n, c, h, w] (fp32) = (x[n, h, w, c] - min_c) / (max_c - min_c)"""
+        self._act(x)
+        N, H, W = x.shape[0], x.shape[1], x.shape[2]
+        assert out.dtype == torch.float32 and tuple(out.shape) == (N, c_real, H, W) and out.is_contiguous()
+        check(self.lib.dg_normalise_planar(self.dg, _ptr(x), N, H, W, pix_layout(x)[0], c_real, _ptr(minmax), _ptr(out),
+                                           self._stream()), "dg_normalise_planar")
+
+    def ssim_level(self, X, Y, params, sums):
+        assert X.dtype == torch.float32 and X.shape == Y.shape and X.is_contiguous() and Y.is_contiguous()
+        planes, H, W = X.shape[0] * X.shape[1], X.shape[2], X.shape[3]
+        assert sums.dtype == torch.float32 and sums.numel() == 2 * planes
+        check(self.lib.dg_ssim_level(_ptr(X), _ptr(Y), planes, H, W, C.byref(params), _ptr(sums), self._stream()), "dg_ssim_level")
+
+    def avgpool2(self, inp, out):
+        assert inp.dtype == torch.float32 and out.dtype == torch.float32 and inp.is_contiguous() and out.is_contiguous()
+        planes, H, W = inp.shape[0] * inp.shape[1], inp.shape[2], inp.shape[3]
+        check(self.lib.dg_avgpool2(_ptr(inp), _ptr(out), planes, H, W, self._stream()), "dg_avgpool2")
+
+    def msssim_finish(self, sums, levels, planes, combine, out):
+        assert sums.numel() == levels * planes * 2 and out.dtype == torch.float32
+        check(self.lib.dg_msssim_finish(_ptr(sums), levels, planes, C.byref(combine), _ptr(out), self._stream()), "dg_msssim_finish")
+
     def sum_strided(self, inp, n, stride, scale, out):
         assert inp.dtype == torch.float32 and out.dtype == torch.float32
         check(self.lib.dg_sum_strided(_ptr(inp), n, stride, float(scale), _ptr(out), self._stream()), "dg_sum_strided")

@@ -203,6 +203,41 @@ int dg_nhwc_to_nchw(int dtype, const void* src, int64_t lds, float* dst, int N, 
 /* fp32 -> dtype cast of n elements (weight shadows) */
 int dg_cast(int dtype, const float* src, void* dst, int64_t n, void* stream);
 
+/* ---- MS-SSIM of the per-step metrics pass.  Replaces `SSIM_Loss(x, y, device)`
+ * (DoWnGAN/GAN/losses.py:12-38, called per batch from mlflow_tools/mlflow_epoch.py:53-63 at wasserstein.py:140), which
+ * min-max normalises each channel over the batch and evaluates `pytorch_msssim.MS_SSIM(win_size=7, data_range=1,
+ * channel=2)` (third-party, unpinned: the kernels follow its published algorithm; see oracle/msssim.py). */
+#define DG_SSIM_MAX_CH 8
+#define DG_SSIM_MAX_WIN 11
+#define DG_SSIM_MAX_LEVELS 5
+#define DG_MINMAX_PARTS 256
+typedef struct dg_ssim_params {
+  int win;                      /* Gaussian window length (reference: 7) */
+  float g[DG_SSIM_MAX_WIN];     /* normalised 1-D Gaussian, sigma 1.5 (pytorch_msssim _fspecial_gauss_1d) */
+  float C1, C2;                 /* (K1*data_range)^2, (K2*data_range)^2 with K = (0.01, 0.03) */
+} dg_ssim_params;
+typedef struct dg_msssim_combine {
+  float inv_count[DG_SSIM_MAX_LEVELS];  /* 1 / ((H_l-win+1)*(W_l-win+1)) */
+  float weight[DG_SSIM_MAX_LEVELS];     /* 0.0448, 0.2856, 0.3001, 0.2363, 0.1333 */
+} dg_msssim_combine;
+/* per-channel min / max over `pixels` ld-strided pixels (first C channels): partial[DG_MINMAX_PARTS][C][2]
+ * (losses.py:15-18, 23-26: x[:, c].min() / .max() over the whole batch) */
+int dg_minmax_partial(int dtype, const void* x, int64_t pixels, int64_t ld, int C, float* partial, void* stream);
+/* minmax[C][2] = {min, max} over the partials */
+int dg_minmax_finish(const float* partial, int C, float* minmax, void* stream);
+/* out[n][c][h][w] (planar fp32) = (x[n][h][w][c] - min_c) / (max_c - min_c)   (losses.py:20-21, 28-29) */
+int dg_normalise_planar(int dtype, const void* x, int N, int H, int W, int64_t ld, int C, const float* minmax,
+                        float* out, void* stream);
+/* one scale of pytorch_msssim `_ssim`: sums[plane][0] += sum of the SSIM map, sums[plane][1] += sum of the CS map over
+ * the 'valid' (H-win+1)x(W-win+1) window positions of every HxW plane of X, Y (planar fp32) */
+int dg_ssim_level(const float* X, const float* Y, int planes, int H, int W, const dg_ssim_params* p, float* sums,
+                  void* stream);
+/* avg_pool2d(kernel 2, stride 2, padding = size % 2 per dim, padded zeros counted) between scales (`ms_ssim`) */
+int dg_avgpool2(const float* in, float* out, int planes, int H, int W, void* stream);
+/* out[0] = sum over planes of prod_l relu(mean_l)^weight_l, mean_l = CS mean for l < levels-1, SSIM mean at the last
+ * scale; sums is [levels][planes][2].  The caller divides by the (global) plane count (`size_average=True`). */
+int dg_msssim_finish(const float* sums, int levels, int planes, const dg_msssim_combine* cmb, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

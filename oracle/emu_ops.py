@@ -205,6 +205,45 @@ class EmuOps:
     def sqdiff(self, a, b, acc):
         acc[0] += ((a.float() - b.float()) ** 2).sum()
 
+    # MS-SSIM pieces: plain torch restatements of the kernel contracts of csrc/metrics.hip
+    def minmax(self, x, c_real, partial, minmax):
+        v = x[..., :c_real].float().reshape(-1, c_real)
+        mm = minmax.view(c_real, 2)
+        mm[:, 0] = v.amin(0)
+        mm[:, 1] = v.amax(0)
+
+    def normalise_planar(self, x, c_real, minmax, out):
+        mm = minmax.view(c_real, 2)
+        v = x[..., :c_real].float().permute(0, 3, 1, 2)
+        out.copy_((v - mm[:, 0].view(1, -1, 1, 1)) / (mm[:, 1] - mm[:, 0]).view(1, -1, 1, 1))
+
+    def ssim_level(self, X, Y, params, sums):
+        win = torch.tensor([params.g[i] for i in range(params.win)], dtype=torch.float32)
+
+        def gf(t):
+            Cn = t.shape[1]
+            w = win.view(1, 1, -1, 1).repeat(Cn, 1, 1, 1)
+            t = torch.nn.functional.conv2d(t, w, groups=Cn)
+            return torch.nn.functional.conv2d(t, w.transpose(2, 3), groups=Cn)
+        mu1, mu2 = gf(X), gf(Y)
+        s1, s2, s12 = gf(X * X) - mu1 * mu1, gf(Y * Y) - mu2 * mu2, gf(X * Y) - mu1 * mu2
+        cs = (2 * s12 + params.C2) / (s1 + s2 + params.C2)
+        ss = ((2 * mu1 * mu2 + params.C1) / (mu1 * mu1 + mu2 * mu2 + params.C1)) * cs
+        sm = sums.view(-1, 2)
+        sm[:, 0] += ss.flatten(2).sum(-1).flatten()
+        sm[:, 1] += cs.flatten(2).sum(-1).flatten()
+
+    def avgpool2(self, inp, out):
+        out.copy_(torch.nn.functional.avg_pool2d(inp, 2, padding=[inp.shape[2] % 2, inp.shape[3] % 2]))
+
+    def msssim_finish(self, sums, levels, planes, combine, out):
+        sm = sums.view(levels, planes, 2)
+        v = torch.ones(planes)
+        for l in range(levels):
+            term = torch.relu((sm[l, :, 0] if l == levels - 1 else sm[l, :, 1]) * combine.inv_count[l])
+            v = v * term ** combine.weight[l]
+        out[0] = v.sum()
+
     def sum_strided(self, inp, n, stride, scale, out):
         out[0] = inp.reshape(-1)[:n * stride:stride].sum() * scale
 

@@ -113,6 +113,10 @@ def test_metrics_pass_matches_reference_golden():
     m = eng.metrics_pass(xc, xf)
     for k, v in gold["forward"]["metrics"].items():
         assert abs(m[k] - v) <= 1e-5 * max(abs(v), 1.0) + 2e-7, (k, m[k], v)
+    from oracle import msssim as om             # MS-SSIM: unpinned third-party metric, checked against the restatement
+    with torch.no_grad():
+        ref = om.ssim_loss(tf, orc.G(tc))
+    assert abs(m["MSSSIM"] - ref) < 1e-5, (m["MSSSIM"], ref)
 
 
 def test_state_dict_roundtrip():

@@ -76,6 +76,14 @@ def test_metrics_pass_matches_reference_golden(name):
     m = eng.metrics_pass(xc, xf)
     for k, v in gold["forward"]["metrics"].items():
         assert abs(m[k] - v) <= 1e-4 * max(abs(v), abs(gold["steps"][0]["c_real_mean"])), (k, m[k], v)
+    # MS-SSIM (third-party in the reference, parity unpinned): against the oracle's restatement on the oracle's own G(x)
+    from oracle import msssim as om
+    from oracle import ref_step
+    pg, pc, tc, tf = _
+    PG = {k: torch.from_numpy(v) for k, v in pg.items()}
+    with torch.no_grad():
+        ref = om.ssim_loss(tf, ref_step.generator_forward(PG, tc, c["num_res_blocks"]))
+    assert m["MSSSIM"] is not None and abs(m["MSSSIM"] - ref) < 1e-4, (m["MSSSIM"], ref)
 
 
 def test_fp32_gradients_match_float64_oracle():
