@@ -42,6 +42,8 @@ class WassersteinGAN:
 
     def _to_native(self, e, coarse, fine):
         o = e.ops
+        if hasattr(coarse, "nhwc"):            # dataloader.NativeBatch: already in native layout (ResidentLoader)
+            return coarse.nhwc, fine.nhwc
         xc, xf = self._stage
         o.nchw_to_nhwc(coarse.to(device=o.device, dtype=torch.float32).contiguous(), xc)
         o.nchw_to_nhwc(fine.to(device=o.device, dtype=torch.float32).contiguous(), xf)

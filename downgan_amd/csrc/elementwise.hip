@@ -461,3 +461,36 @@ extern "C" int dg_repack_conv_weights(int dtype, int kind, const float* master, 
 }
 
 extern "C" const char* dg_version(void) { return "downgan_hip 0.1.0 (gfx950)"; }
+
+// ------------------------------------------------------------------ resident-dataset minibatch gather (data feed)
+// src: [n][HW][c_real] (compute dtype, real channels only, whole dataset resident in HBM); dst: [B][HW][c_pad] native
+// activations (padding channels zero); one 16-byte destination chunk per thread.
+template <typename T>
+__global__ void gather_samples_kernel(const T* src, long long HW, int c_real, const long long* idx, int B, T* dst, int c_pad) {
+  constexpr int EPC = DT<T>::EPC;
+  const int cch = c_pad / EPC;
+  const long long per = HW * cch, total = per * B;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    const long long r = i - (long long)b * per;
+    const long long p = r / cch;
+    const int c0 = (int)(r - p * cch) * EPC;
+    const T* s = src + (idx[b] * HW + p) * c_real;
+    float v[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v[e] = (c0 + e < c_real) ? ld_elem(s + c0 + e) : 0.f;
+    T* d = dst + ((long long)b * HW + p) * c_pad + c0;
+    if constexpr (EPC == 8) { st4(d, v); st4(d + 4, v + 4); } else { st4(d, v); }
+  }
+}
+extern "C" int dg_gather_samples(int dtype, const void* src, int64_t HW, int c_real, const int64_t* idx, int B, void* dst,
+                                 int c_pad, void* stream) {
+  if (!src || !idx || !dst || HW <= 0 || c_real <= 0 || B <= 0 || c_pad < c_real || c_pad % 8) return DG_ERR_BAD_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int epc = dtype == DG_F32 ? 4 : 8;
+  const unsigned nb = ew_blocks((long long)HW * (c_pad / epc) * B);
+  if (dtype == DG_F32) hipLaunchKernelGGL(gather_samples_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)src, (long long)HW, c_real, (const long long*)idx, B, (float*)dst, c_pad);
+  else if (dtype == DG_BF16) hipLaunchKernelGGL(gather_samples_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)src, (long long)HW, c_real, (const long long*)idx, B, (bf16_t*)dst, c_pad);
+  else return DG_ERR_BAD_DTYPE;
+  return dg_check_launch();
+}

@@ -204,3 +204,54 @@ extern "C" int dg_msssim_finish(const float* sums, int levels, int planes, const
   hipLaunchKernelGGL(msssim_finish_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), sums, levels, planes, *cmb, out);
   return dg_check_launch();
 }
+
+// ------------------------------------------------------------------ divergence / vorticity metrics (losses.py:119-193)
+// One pass over both NHWC tensors: forward differences of channel 0 along H and channel 1 along W on the [1:, 1:] window,
+// div = dudy + dvdx, vort = dvdx - dudy, and for each of the two fields the five moments
+// {sum r, sum r^2, sum f, sum f^2, sum r*f} (double) from which the host forms the std-normalised MSE.
+template <typename T>
+__global__ __launch_bounds__(256) void div_vort_kernel(const T* hr, long long ldr, const T* fk, long long ldf, int N, int H, int W, double* sums) {
+  __shared__ double red[4][10];
+  double s[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) s[q] = 0.0;
+  const long long per = (long long)(H - 1) * (W - 1), total = (long long)N * per;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / per, r = i - n * per;
+    const int y = (int)(r / (W - 1)) + 1, x = (int)(r % (W - 1)) + 1;
+    const long long p = (n * H + y) * W + x;
+    float d[2], v[2];
+    {
+      const T* a = hr + p * ldr;
+      const float dudy = ld_elem(a) - ld_elem(a - (long long)W * ldr), dvdx = ld_elem(a + 1) - ld_elem(a - ldr + 1);
+      d[0] = dudy + dvdx; v[0] = dvdx - dudy;
+    }
+    {
+      const T* a = fk + p * ldf;
+      const float dudy = ld_elem(a) - ld_elem(a - (long long)W * ldf), dvdx = ld_elem(a + 1) - ld_elem(a - ldf + 1);
+      d[1] = dudy + dvdx; v[1] = dvdx - dudy;
+    }
+    s[0] += d[0]; s[1] += (double)d[0] * d[0]; s[2] += d[1]; s[3] += (double)d[1] * d[1]; s[4] += (double)d[0] * d[1];
+    s[5] += v[0]; s[6] += (double)v[0] * v[0]; s[7] += v[1]; s[8] += (double)v[1] * v[1]; s[9] += (double)v[0] * v[1];
+  }
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_xor(s[q], o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = s[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+extern "C" int dg_div_vort_sums(int dtype, const void* hr, int64_t ldhr, const void* fake, int64_t ldfake, int N, int H, int W,
+                                double* sums, void* stream) {
+  if (!hr || !fake || !sums || N <= 0 || H < 2 || W < 2 || ldhr < 2 || ldfake < 2) return DG_ERR_BAD_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long total = (long long)N * (H - 1) * (W - 1);
+  long long nb = (total + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  if (dtype == DG_F32) hipLaunchKernelGGL(div_vort_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)hr, (long long)ldhr, (const float*)fake, (long long)ldfake, N, H, W, sums);
+  else if (dtype == DG_BF16) hipLaunchKernelGGL(div_vort_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)hr, (long long)ldhr, (const bf16_t*)fake, (long long)ldfake, N, H, W, sums);
+  else return DG_ERR_BAD_DTYPE;
+  return dg_check_launch();
+}

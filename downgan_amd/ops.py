@@ -322,6 +322,23 @@ class HipOps:
         assert sums.numel() == levels * planes * 2 and out.dtype == torch.float32
         check(self.lib.dg_msssim_finish(_ptr(sums), levels, planes, C.byref(combine), _ptr(out), self._stream()), "dg_msssim_finish")
 
+    def gather_samples(self, store, idx, dst):
+        """dst[b] (NHWC, padded channels) = store[idx[b]] ([n, H, W, c_real], compute dtype)."""
+        self._act(dst)
+        assert store.dtype == self.tdtype and store.is_contiguous() and store.dim() == 4 and dst.is_contiguous()
+        assert idx.dtype == torch.int64 and idx.is_cuda and idx.numel() == dst.shape[0]
+        assert tuple(store.shape[1:3]) == tuple(dst.shape[1:3]) and store.shape[3] <= dst.shape[3]
+        check(self.lib.dg_gather_samples(self.dg, _ptr(store), store.shape[1] * store.shape[2], store.shape[3], _ptr(idx), idx.numel(),
+                                         _ptr(dst), dst.shape[3], self._stream()), "dg_gather_samples")
+
+    def div_vort_sums(self, hr, fake, sums):
+        """sums[10] (float64, pre-zeroed) += moments of the divergence / vorticity of hr and fake (NHWC, channels 0, 1)."""
+        self._act(hr); self._act(fake)
+        assert hr.shape == fake.shape and sums.dtype == torch.float64 and sums.numel() == 10
+        N, H, W = hr.shape[0], hr.shape[1], hr.shape[2]
+        check(self.lib.dg_div_vort_sums(self.dg, _ptr(hr), pix_layout(hr)[0], _ptr(fake), pix_layout(fake)[0], N, H, W, _ptr(sums),
+                                        self._stream()), "dg_div_vort_sums")
+
     def sum_strided(self, inp, n, stride, scale, out):
         assert inp.dtype == torch.float32 and out.dtype == torch.float32
         check(self.lib.dg_sum_strided(_ptr(inp), n, stride, float(scale), _ptr(out), self._stream()), "dg_sum_strided")

@@ -238,6 +238,20 @@ int dg_avgpool2(const float* in, float* out, int planes, int H, int W, void* str
  * scale; sums is [levels][planes][2].  The caller divides by the (global) plane count (`size_average=True`). */
 int dg_msssim_finish(const float* sums, int levels, int planes, const dg_msssim_combine* cmb, float* out, void* stream);
 
+/* Finite-difference physics metrics `divergence_loss` / `vorticity_loss` (DoWnGAN/GAN/losses.py:119-193; known answers in
+ * DoWnGAN/GAN/tests/test_losses.py:75-116).  sums[10] (double, pre-zeroed) += {sum r, sum r^2, sum f, sum f^2, sum r*f} of
+ * the divergence (dudy + dvdx) of `hr` (r) and `fake` (f), then the same five of the vorticity (dvdx - dudy); channel 0 = u,
+ * channel 1 = v, differences on the [1:, 1:] window.  The host forms MSE(r/std(r), f/std(f)) with the unbiased std. */
+int dg_div_vort_sums(int dtype, const void* hr, int64_t ldhr, const void* fake, int64_t ldfake, int N, int H, int W,
+                     double* sums, void* stream);
+
+/* Data feed.  The reference keeps the whole train set on the device (stage.py:28-31) and lets a
+ * shuffling `DataLoader` index it through `NetCDFSR.__getitem__` (dataloader.py:26-33, stage.py:69-72).  Here the set stays
+ * resident in HBM as [n][H*W][c_real] in the compute dtype and one launch forms a minibatch in native layout:
+ * dst[b][p][c] = src[idx[b]][p][c] for c < c_real, 0 for the padding channels up to c_pad.  idx: B int64 on the device. */
+int dg_gather_samples(int dtype, const void* src, int64_t HW, int c_real, const int64_t* idx, int B, void* dst, int c_pad,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,23 @@ def test_reference_named_metric_functions():
     assert set(L.metrics_to_calculate) == {"MAE", "MSE", "MSSSIM", "Wass"}
 
 
+def test_divergence_and_vorticity_known_answers_and_oracle():
+    """losses.py:119-193 through the C ABI: the reference's own known answers (test_losses.py:75-116) and the oracle on
+    random fields (relative 1e-5: the kernel accumulates the moments in double, the reference in fp32)."""
+    import numpy as np
+    from downgan_amd.GAN import losses as L
+    from oracle import physics
+    hr, fake = physics.reference_test_fixture()
+    assert np.isclose(L.divergence_loss(hr, fake), physics.KNOWN["divergence"], atol=physics.KNOWN["atol"])
+    assert np.isclose(L.vorticity_loss(hr, fake), physics.KNOWN["vorticity"], atol=physics.KNOWN["atol"])
+    assert abs(L.divergence_loss(hr, fake) - physics.divergence_loss(hr, fake)) < 1e-6
+    x, y = fields(3, 2, 97, 130, seed=8, noise=0.5)
+    for nat, orc in ((L.divergence_loss, physics.divergence_loss), (L.vorticity_loss, physics.vorticity_loss)):
+        a, b = nat(x, y), orc(x, y)
+        assert abs(a - b) < 1e-5 * abs(b) + 1e-7, (a, b)
+    assert abs(L.divergence_loss(x, x)) < 1e-9
+
+
 def test_cabi_rejects_bad_arguments():
     import ctypes as C
     from downgan_amd import _lib
