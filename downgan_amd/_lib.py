@@ -85,6 +85,8 @@ _PROTOS = {
     "dg_msssim_finish": [_vp, _i, _i, C.POINTER(MsssimCombine), _vp, _vp],
     "dg_div_vort_sums": [_i, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp],
     "dg_gather_samples": [_i, _vp, _i64, _i, _vp, _i, _vp, _i, _vp],
+    "dg_lowpass5": [_i, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp],
+    "dg_lowpass5_adjoint": [_i, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp],
 }
 EXPORTS = ["dg_version"] + list(_PROTOS)
 

@@ -657,3 +657,61 @@ class TrainEngine:
             out["content_loss"] = d["l1_sum"] / (self.n_real_elems * self.world)
             out["g_loss"] = -d["g_c_fake_mean"] * hp.gamma + hp.content_lambda * out["content_loss"]
         return out
+
+
+class TrainEngineFS(TrainEngine):
+    """Frequency-separation variant (DoWnGAN/GAN/wasserstein_fs.py:28-92, hyperparams.py:31-35):
+    ``low(x)`` = 5x5 box mean with replicated borders, ``high = x - low``.  The critic (incl. the gradient penalty) sees the
+    high-pass parts, the content loss compares the low-pass parts.  Everything else is the parent's hot path."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        o = self.ops
+        shape = self.xhat.shape
+        self.real_high, self.fake_high = o.zeros(*shape), o.zeros(*shape)
+        self.real_low = self.fake_low = self.tbuf = None
+
+    def critic_iteration(self, coarse, fine, alpha, apply_update=True):
+        """wasserstein_fs.py:28-60."""
+        o, hp, C, B = self.ops, self.hp, self.C, self.B
+        bg = B * self.world
+        fake = self.G.forward(coarse, save=False)                 # :36
+        o.lowpass5(fake, high=self.fake_high)                     # :37,40
+        o.lowpass5(fine, high=self.real_high)                     # :38,41
+        C.P.zero_grad()                                           # :49
+        out = C.forward(self.real_high)                           # :43
+        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
+        C.backward(self.real_high, -1.0 / bg)
+        out = C.forward(self.fake_high)                           # :44
+        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
+        C.backward(self.fake_high, 1.0 / bg)
+        o.gp_interp(self.real_high, self.fake_high, alpha, self.xhat)          # :46 -> _gp(real_high, fake_high)
+        C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg)
+        if apply_update:
+            self._allreduce_and_step(C.P)                         # :57-60
+
+    def generator_iteration(self, coarse, fine, apply_update=True):
+        """wasserstein_fs.py:63-92: g_loss = -gamma*mean C(fake_high) + content_lambda*L1(fake_low, real_low); the gradient
+        reaches ``fake`` through both branches: d fake = d_high + low^T(g_L1 - d_high)."""
+        o, hp, C, G, B = self.ops, self.hp, self.C, self.G, self.B
+        bg = B * self.world
+        if self.dfake is None:
+            self.dfake = o.zeros(*self.G.fake.shape)
+        if self.tbuf is None:
+            self.real_low, self.fake_low, self.tbuf = (o.zeros(*self.xhat.shape) for _ in range(3))
+        G.P.zero_grad()                                           # :70
+        fake = G.forward(coarse, save=True)                       # :72
+        o.lowpass5(fake, low=self.fake_low, high=self.fake_high)  # :73,76
+        o.lowpass5(fine, low=self.real_low)                       # :74
+        out = C.forward(self.fake_high)                           # :79
+        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("g_c_fake_mean"))
+        C.backward(self.fake_high, -hp.gamma / bg, wgrad=False, dx=self.gbuf)  # d(-gamma*mean c_fake)/d fake_high
+        self._sc("l1_sum").zero_()
+        o.l1(self.fake_low, self.real_low, self._sc("l1_sum"), grad=self.tbuf,
+             grad_scale=hp.content_lambda / (self.n_real_elems * self.world))  # :86
+        o.axpby(self.tbuf, self.tbuf, 1.0, self.gbuf, -1.0)        # g_L1 - d_high
+        o.lowpass5_adjoint(self.tbuf, self.dfake)
+        o.axpby(self.dfake, self.dfake, 1.0, self.gbuf, 1.0)       # + d_high
+        G.backward(coarse, self.dfake)                            # :88
+        if apply_update:
+            self._allreduce_and_step(G.P)                         # :91

@@ -322,6 +322,23 @@ class HipOps:
         assert sums.numel() == levels * planes * 2 and out.dtype == torch.float32
         check(self.lib.dg_msssim_finish(_ptr(sums), levels, planes, C.byref(combine), _ptr(out), self._stream()), "dg_msssim_finish")
 
+    # ------------------------------------------------------------------ frequency separation
+    def lowpass5(self, x, low=None, high=None):
+        """low = 5x5 box mean with replicated borders, high = x - low (either may be None); NHWC, all padded channels."""
+        self._act(x)
+        N, H, W, Cc = x.shape
+        for t in (low, high):
+            assert t is None or (self._act(t) is t and t.shape == x.shape)
+        check(self.lib.dg_lowpass5(self.dg, _ptr(x), pix_layout(x)[0], N, H, W, Cc, _ptr(low), pix_layout(low)[0] if low is not None else 0,
+                                   _ptr(high), pix_layout(high)[0] if high is not None else 0, self._stream()), "dg_lowpass5")
+
+    def lowpass5_adjoint(self, g, out):
+        self._act(g); self._act(out)
+        assert g.shape == out.shape and g.data_ptr() != out.data_ptr()
+        N, H, W, Cc = g.shape
+        check(self.lib.dg_lowpass5_adjoint(self.dg, _ptr(g), pix_layout(g)[0], N, H, W, Cc, _ptr(out), pix_layout(out)[0], self._stream()),
+              "dg_lowpass5_adjoint")
+
     def gather_samples(self, store, idx, dst):
         """dst[b] (NHWC, padded channels) = store[idx[b]] ([n, H, W, c_real], compute dtype)."""
         self._act(dst)

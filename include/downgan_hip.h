@@ -252,6 +252,16 @@ int dg_div_vort_sums(int dtype, const void* hr, int64_t ldhr, const void* fake, 
 int dg_gather_samples(int dtype, const void* src, int64_t HW, int c_real, const int64_t* idx, int B, void* dst, int c_pad,
                       void* stream);
 
+/* Frequency-separation variant (DoWnGAN/GAN/wasserstein_fs.py:36-46,73-86, hyperparams.py:31-35):
+ * low = AvgPool2d(5, stride 1)(ReplicationPad2d(2)(x)) and/or high = x - low of an NHWC tensor (C padded channels,
+ * multiple of 8); either output may be NULL. */
+int dg_lowpass5(int dtype, const void* x, int64_t ldx, int N, int H, int W, int C, void* low, int64_t ldl, void* high,
+                int64_t ldh, void* stream);
+/* out = low^T(g): the adjoint of the operator above (what autograd applies in the reference's `g_loss.backward()`,
+ * wasserstein_fs.py:88, to reach `fake` through `fake_low` and `fake_high`). */
+int dg_lowpass5_adjoint(int dtype, const void* g, int64_t ldg, int N, int H, int W, int C, void* out, int64_t ldo,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

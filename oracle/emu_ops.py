@@ -244,6 +244,25 @@ class EmuOps:
             v = v * term ** combine.weight[l]
         out[0] = v.sum()
 
+    # frequency separation (csrc/freqsep.hip contracts)
+    @staticmethod
+    def _lp(v):
+        return torch.nn.functional.avg_pool2d(torch.nn.functional.pad(v, (2, 2, 2, 2), mode="replicate"), 5, stride=1)
+
+    def lowpass5(self, x, low=None, high=None):
+        v = x.float().permute(0, 3, 1, 2)
+        lo = self._lp(v)
+        if low is not None:
+            low.copy_(lo.permute(0, 2, 3, 1).to(low.dtype))
+        if high is not None:
+            high.copy_((v - lo).permute(0, 2, 3, 1).to(high.dtype))
+
+    def lowpass5_adjoint(self, g, out):
+        v = g.float().permute(0, 3, 1, 2).clone().requires_grad_(False)
+        probe = torch.zeros_like(v, requires_grad=True)
+        (adj,) = torch.autograd.grad(self._lp(probe), probe, grad_outputs=v)
+        out.copy_(adj.permute(0, 2, 3, 1).to(out.dtype))
+
     def sum_strided(self, inp, n, stride, scale, out):
         out[0] = inp.reshape(-1)[:n * stride:stride].sum() * scale
 

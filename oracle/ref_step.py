@@ -219,3 +219,57 @@ class OracleTrainer:
             out.update(g)
         self.num_steps += 1
         return out
+
+
+# --------------------------------------------------------------------------- frequency-separation variant
+def lowpass(x):
+    """config/hyperparams.py:31-35: ``low(rf(x))`` = AvgPool2d(5, stride=1, padding=0) after ReplicationPad2d(2)."""
+    return F.avg_pool2d(F.pad(x, (2, 2, 2, 2), mode="replicate"), 5, stride=1, padding=0)
+
+
+class OracleTrainerFS(OracleTrainer):
+    """Restates WassersteinGANFS (GAN/wasserstein_fs.py:28-130): the critic sees the high-pass parts ``x - low(x)`` of the
+    real and generated fields (also inside the gradient penalty), the content loss compares the low-pass parts.
+
+    Parity status of this variant: UNPINNED.  The reference module cannot be imported (it imports ``DoWnGAN.gen_grid_plots``,
+    a bare ``hyperparams`` and an undefined ``config``, wasserstein_fs.py:2-10, and no caller reads ``hp.freq_sep``), so no
+    golden can be generated from it; this follows the text of its two iteration methods."""
+
+    def critic_iteration(self, coarse, fine, alpha, apply_update=True):
+        """wasserstein_fs.py:28-60."""
+        hp = self.hp
+        with torch.no_grad():
+            fake = self.G(coarse)
+            fake_high = fake - lowpass(fake)
+            real_high = fine - lowpass(fine)
+        c_real = self.C(real_high)
+        c_fake = self.C(fake_high)
+        gp_ret = gradient_penalty(self.PC, real_high, fake_high, alpha, hp)
+        gradient_penalty_term = hp.gp_lambda * gp_ret                     # :45
+        c_real_mean, c_fake_mean = torch.mean(c_real), torch.mean(c_fake)
+        critic_loss = c_fake_mean - c_real_mean + gradient_penalty_term
+        names = list(self.PC)
+        gl = torch.autograd.grad(critic_loss, [self.PC[k] for k in names], allow_unused=True)
+        grads = {k: (g if g is not None else torch.zeros_like(self.PC[k])) for k, g in zip(names, gl)}
+        if apply_update:
+            self.C_opt.step(self.PC, grads)
+        return {"c_real_mean": c_real_mean.item(), "c_fake_mean": c_fake_mean.item(), "gp_ret": gp_ret.item(),
+                "gradient_penalty": gradient_penalty_term.item(), "critic_loss": critic_loss.item(),
+                "w_estimate": (c_real_mean - c_fake_mean).item()}, grads
+
+    def generator_iteration(self, coarse, fine, apply_update=True):
+        """wasserstein_fs.py:63-92."""
+        hp = self.hp
+        fake = self.G(coarse)
+        fake_low = lowpass(fake)
+        real_low = lowpass(fine)
+        fake_high = fake - fake_low
+        c_fake = self.C(fake_high)
+        cl = content_loss(fake_low, real_low)                             # :86
+        g_loss = -torch.mean(c_fake) * hp.gamma + hp.content_lambda * cl
+        names = list(self.PG)
+        gl = torch.autograd.grad(g_loss, [self.PG[k] for k in names])
+        grads = dict(zip(names, gl))
+        if apply_update:
+            self.G_opt.step(self.PG, grads)
+        return {"g_loss": g_loss.item(), "content_loss": cl.item(), "g_c_fake_mean": torch.mean(c_fake).item()}, grads
