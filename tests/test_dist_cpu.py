@@ -39,9 +39,10 @@ def _worker(rank, world, port, outdir):
     dist = Dist("gloo")
     eng, _ = _build(1, dist, global_b=2)
     xc, xf, alpha = _data(rank, rank + 1)
+    metrics = eng.metrics_pass(xc, xf)          # before the update: global-batch min/max (all-reduce MIN/MAX) and means
     ran_g = eng.train_step(xc, xf, alpha)
     scal = eng.read_scalars(ran_g)
-    torch.save({"C": eng.C.state_dict(), "G": eng.G.state_dict(), "scal": scal}, os.path.join(outdir, f"r{rank}.pt"))
+    torch.save({"C": eng.C.state_dict(), "G": eng.G.state_dict(), "scal": scal, "metrics": metrics}, os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
 
 
@@ -49,6 +50,7 @@ def test_two_ranks_equal_single_process():
     torch.set_num_threads(4)
     eng, _ = _build(2)
     xc, xf, alpha = _data(0, 2)
+    ref_metrics = eng.metrics_pass(xc, xf)
     ran_g = eng.train_step(xc, xf, alpha)
     ref_scal = eng.read_scalars(ran_g)
     ref_c, ref_g = eng.C.state_dict(), eng.G.state_dict()
@@ -65,3 +67,6 @@ def test_two_ranks_equal_single_process():
         assert torch.allclose(r0["G"][k], ref_g[k], rtol=0, atol=2e-6), k
     for k in ("critic_loss", "gp_ret", "g_loss", "content_loss", "c_real_mean"):
         assert abs(r0["scal"][k] - ref_scal[k]) <= 1e-5 * max(1.0, abs(ref_scal[k])), (k, r0["scal"][k], ref_scal[k])
+    for k in ("MAE", "MSE", "Wass", "MSSSIM"):          # metrics pass of the sharded batch == whole batch in one process
+        assert r0["metrics"][k] == r1["metrics"][k], k
+        assert abs(r0["metrics"][k] - ref_metrics[k]) <= 1e-5 * max(1.0, abs(ref_metrics[k])), (k, r0["metrics"][k], ref_metrics[k])
