@@ -730,7 +730,12 @@ extern "C" int dg_debug_stamps(unsigned long long* out) {
 #else
 #define STAMP(v) do { } while (0)
 #endif
-template <typename T>
+// S2 = stride-2 forward on the same machinery.  out(y,x) = sum_{r,s} in(2y+r-1, 2x+s-1) w(r,s): split the input into its four
+// parity planes (py,px) = (row & 1, col & 1) of 2x2 blocks; tap r reads plane py = (r != 1) at block offset (r == 0 ? -1 : 0),
+// so every tap is a UNIT-stride shift in block coordinates.  The K loop runs over (plane, channel block) pairs; the patch
+// of a pair is the 17x17 blocks of that plane (gathered with stride 2 straight from the NHWC tensor, 256-byte rows), and
+// the pair's taps are the 1 / 2 / 2 / 4 taps that read the plane (a.tap_* are grouped by plane by the launcher).
+template <typename T, bool S2>
 __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int tiles_x, int tiles_y) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int ES = (int)sizeof(T);
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   const int c0 = tile_c * BC;
   const int cc = tid & 15, r0 = tid >> 4;        // r0 in [0,32)
 
-  const int sy_base = ty0 - 1 > 0 ? ty0 - 1 : 0;
+  const int sy_base = S2 ? (ty0 > 0 ? 2 * (ty0 - 1) : 0) : (ty0 - 1 > 0 ? ty0 - 1 : 0);
   unsigned woff[NWL];                            // lane's source offset for DMA piece i: row r0+32i, chunk cc ^ (r0 & 15)
 #pragma unroll
   for (int i = 0; i < NWL; ++i) {
@@ -769,8 +774,18 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
   const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
 
+  const int ncbr = a.cch / KC;                   // channel blocks of 128 (64 for fp32) reduction channels
+  // (plane, channel block) pairs are numbered plane-major; planes hold 1, 2, 2, 4 taps starting at tap 0, 1, 3, 5
+  auto plane_of = [&](int vcb) { return S2 ? (int)(vcb >= ncbr) + (int)(vcb >= 2 * ncbr) + (int)(vcb >= 3 * ncbr) : 0; };
+  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : a.ntaps; };
+  auto tap_code = [&](int vcb, int tap) {
+    const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap;
+    return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
+  };
   u32x4_t rp[NPL];
-  auto load_patch = [&](int cb) {
+  auto load_patch = [&](int vcb) {
+    const int plane = plane_of(vcb), cb = vcb - plane * ncbr;
+    const int ppy = plane >> 1, ppx = plane & 1;
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
     // offsets are recomputed per channel block (once per ntaps steps) instead of living in 11 registers; the empty
     // asm keeps the compiler from hoisting them back out of the step loop
@@ -780,7 +795,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
     for (int i = 0; i < NPL; ++i) {
       const int pr = r0v + 32 * i;
       const int py = pr / PW, px = pr - py * PW;
-      const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+      const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
       const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
       const unsigned off = ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
       rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
@@ -801,9 +816,9 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   // make counted waits stricter.)  m0 is not otherwise used by this kernel.
   i32x4_t w_rs;
   int w_dst0 = 0;
-  auto dma_setup = [&](int cb, int tap, int slot) {
-    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
-    const long long wo = (long long)(code >> 4) * a.Cred + cb * KC * EPC;
+  auto dma_setup = [&](int vcb, int tap, int slot) {
+    const unsigned code = tap_code(vcb, tap);
+    const long long wo = (long long)(code >> 4) * a.Cred + (vcb - plane_of(vcb) * ncbr) * KC * EPC;
     const unsigned long long wbase = (unsigned long long)(Wb + wo * ES);
     w_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wbase);
     w_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(wbase >> 32) & 0xffff);
@@ -838,8 +853,8 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
 
   const int wp = wave & 3, wc = wave >> 2;
   const int l15 = lane & 15, g = lane >> 4;
-  const int ncb = a.cch / KC, ntaps = a.ntaps;
-  const int nsteps = ncb * ntaps;
+  const int ncb = S2 ? 4 * ncbr : ncbr;
+  const int nsteps = ncbr * a.ntaps;
 
   const char* fa_k[4];
 #pragma unroll
@@ -870,9 +885,9 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   //            LDS-DMA W[s+2] -> slot s&1 | mma(blk2) | read blk0 of step s+1 | mma(blk3) | read blk1 of s+1
   // W[s+1] was DMA'd into slot (s+1)&1 after the barrier of step s-1 and published by the barrier of step s.  At a channel-block boundary the single-buffered patch is
   // rewritten after the barrier (every wave holds its last fragments in registers) and a second barrier publishes it.
-  auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps) { t_ = 0; ++c_; } };
-  auto patch_ptr = [&](int tap_) -> const char* {
-    const unsigned code = tap_ < 8 ? (unsigned)((a.tap_lo >> (8 * tap_)) & 0xffull) : (a.tap_hi & 0xffu);
+  auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps_of(c_)) { t_ = 0; ++c_; } };
+  auto patch_ptr = [&](int vcb_, int tap_) -> const char* {
+    const unsigned code = tap_code(vcb_, tap_);
     const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
     return fb_lane + ((wp * 4 + 1 + dy) * PW + 1 + dx) * PITCH;
   };
@@ -887,7 +902,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   barrier_all();
 
   uint4 fa0[4], fb0[4], fa1[4], fb1[4];
-  const char* pb = patch_ptr(0);
+  const char* pb = patch_ptr(0, 0);
   int pa = 0;                        // byte offset of the weight slot being read
   read_frags(fa0, fb0, pa, pb, 0);
   read_frags(fa1, fb1, pa, pb, 1);
@@ -899,8 +914,12 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
     STAMP(tA);
     const bool more = s + 1 < nsteps;
     int ntap = tap + 1, ncbn = cb;
-    if (ntap == ntaps) { ntap = 0; ncbn = cb + 1; }
+    const int ntaps_cb = ntaps_of(cb);
+    if (ntap == ntaps_cb) { ntap = 0; ncbn = cb + 1; }
     const bool swap = ntap == 0 && more;
+    // a one-tap block (plane (0,0) of a stride-2 launch) has no earlier step of its own to fetch the next patch in:
+    // fetched here and stored after this step's barrier (latency exposed, 1 step in 9)
+    if (S2 && ntaps_cb == 1 && cb + 1 < ncb) load_patch(cb + 1);
     __builtin_amdgcn_sched_barrier(0);
     mma_block(fa0, fb0);
     __builtin_amdgcn_sched_barrier(0);
@@ -911,13 +930,13 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
     read_frags(fa1, fb1, pa, pb, 3);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(tB);
-    if (tap == 1 && cb + 1 < ncb) barrier_keep_patch(); else barrier_all();
+    if (tap == 1 && cb + 1 < ncb && ntaps_cb > 1) barrier_keep_patch(); else barrier_all();
     STAMP(tC);
     const bool fetch = s + 2 < nsteps;
     if (fetch) dma_setup(cbw, tapw, s & 1);
     adv(cbw, tapw);
     pa = ((s + 1) & 1) * (BC * KC * 16);
-    pb = patch_ptr(ntap);
+    pb = patch_ptr(ncbn < ncb ? ncbn : 0, ntap);
     if (swap) store_patch();
     // the MFMA blocks stay in straight-line code (no accumulator phis): only the small side operations are conditional.
     // One DMA piece goes behind each row of MFMAs, so its issue cost hides in the gaps between this wave's MFMAs.
@@ -929,7 +948,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
       if (fetch) dma_piece(j);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (tap == 0 && cb + 1 < ncb) load_patch(cb + 1);   // a whole channel block ahead; kept out of the next vmcnt wait
+    if (tap == 0 && cb + 1 < ncb && ntaps_cb > 1) load_patch(cb + 1);   // a whole channel block ahead; kept out of the next vmcnt wait
     __builtin_amdgcn_sched_barrier(0);
     if (swap) barrier_all();                 // publish the new patch before the next step's fragments are read
     read_frags(fa0, fb0, pa, pb, 0);         // (after the last step: a harmless read of valid LDS)
@@ -962,12 +981,12 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
 #endif
 }
 
-template <typename T>
+template <typename T, bool S2>
 static int gg_launch_halo128(GGArgs& a, int N, hipStream_t st) {
   constexpr int LDS_BYTES = 324 * 272 + 2 * 128 * 256;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo128_kernel<T, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return DG_ERR_LAUNCH;
     attr_set = true;
   }
@@ -975,8 +994,36 @@ static int gg_launch_halo128(GGArgs& a, int N, hipStream_t st) {
   a.nct = (unsigned)((a.Nout + 127) / 128);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
   g_last_kinds |= 8;
-  hipLaunchKernelGGL((gg_halo128_kernel<T>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL((gg_halo128_kernel<T, S2>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
   return dg_check_launch();
+}
+
+// Stride-2 forward on the halo kernel: regroup the nine taps (source offsets dy,dx in {-1,0,1} around (2y,2x)) by the parity
+// plane they read, plane-major order (0,0) (0,1) (1,0) (1,1) = 1 + 2 + 2 + 4 taps, and re-express each as a block offset
+// in {-1, 0}.  Returns false (caller falls back to the per-tap kernel) unless the taps are exactly the 3x3 stencil.
+static bool regroup_taps_by_plane(GGArgs& a) {
+  if (a.ntaps != 9) return false;
+  unsigned codes[9], out[9];
+  bool seen[3][3] = {};
+  for (int t = 0; t < 9; ++t) {
+    codes[t] = t < 8 ? (unsigned)((a.tap_lo >> (8 * t)) & 0xffull) : (a.tap_hi & 0xffu);
+    const int dy = (int)(codes[t] & 3u) - 1, dx = (int)((codes[t] >> 2) & 3u) - 1;
+    if (dy < -1 || dy > 1 || dx < -1 || dx > 1 || seen[dy + 1][dx + 1]) return false;
+    seen[dy + 1][dx + 1] = true;
+  }
+  int n = 0;
+  for (int plane = 0; plane < 4; ++plane)
+    for (int t = 0; t < 9; ++t) {
+      const int dy = (int)(codes[t] & 3u) - 1, dx = (int)((codes[t] >> 2) & 3u) - 1;
+      if ((dy != 0) * 2 + (dx != 0) != plane) continue;
+      const unsigned by = dy == -1 ? 0u : 1u, bx = dx == -1 ? 0u : 1u;      // block offset + 1
+      out[n++] = by | (bx << 2) | (codes[t] & 0xf0u);
+    }
+  a.tap_lo = 0; a.tap_hi = 0;
+  for (int t = 0; t < 9; ++t) {
+    if (t < 8) a.tap_lo |= (unsigned long long)out[t] << (8 * t); else a.tap_hi = out[t];
+  }
+  return true;
 }
 
 template <typename T>
@@ -1140,8 +1187,15 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
       a.Hs == a.Hg && a.Ws == a.Wg)
   {
     static const bool no128 = getenv("DG_GG_HALO64") != nullptr;
-    if (!no128 && a.cch % 16 == 0) return gg_launch_halo128<T>(a, N, st);
+    if (!no128 && a.cch % 16 == 0) return gg_launch_halo128<T, false>(a, N, st);
     return gg_launch_halo<T>(a, N, st);
+  }
+  static const bool no_s2halo = getenv("DG_GG_NOS2HALO") != nullptr;
+  if (!no_halo && !no_s2halo && a.sy_mul == 2 && a.sx_mul == 2 && !a.src_ps && a.cch % 16 == 0 && a.Nout > 64 && a.Hg >= 8 &&
+      a.Wg >= 8 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1)
+  {
+    GGArgs b = a;
+    if (regroup_taps_by_plane(b)) return gg_launch_halo128<T, true>(b, N, st);
   }
   if (a.Nout > 64) return gg_launch_t<T, 128, 128, 64, 64>(a, st);
   if (a.Nout > 32) return gg_launch_t<T, 128, 64, 64, 32>(a, st);

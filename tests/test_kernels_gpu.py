@@ -46,6 +46,8 @@ CONVS = [
     (1, 64, 64, 64, 128, 2, False),     # Wo = 32: row-aligned K-steps in wgrad, halo tiles in dgrad
     (1, 32, 32, 64, 256, 1, True),
     (2, 32, 64, 128, 128, 1, False),
+    (2, 48, 80, 256, 128, 2, False),    # stride-2 forward on the halo kernel: 4 parity planes x 2 channel blocks, ragged 24x40 grid
+    (1, 32, 32, 128, 192, 2, False),    # ... with a partial channel tile
 ]
 
 
