@@ -353,7 +353,8 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   static const bool no_rowstep = getenv("DG_WG_GENERIC") != nullptr;
   const bool rs = !no_rowstep && a.Wo % 32 == 0;
   // 64-pixel K-steps halve the barrier count but also the resident workgroups (LDS): measured equal to 32-pixel
-  // steps, so they are opt-in
+  // steps, so they are opt-in.  256x128 / 128x256 tiles (each wave 128x64, 2 workgroups per CU, 25 % fewer staged bytes
+  // per flop) were measured 8-20 % SLOWER than 128x128 with 3 workgroups per CU and are not built.
   static const bool want_kp64 = getenv("DG_WG_KP64") != nullptr;
   const bool kp64 = rs && want_kp64 && a.Wo % 64 == 0 && a.ppb % 64 == 0 && sizeof(T) == 2;
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
