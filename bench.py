@@ -182,6 +182,7 @@ def main():
     scal = eng.read_scalars(True)
 
     roofline = None
+    critic_stack = None
     kernels = {}
     if ops.prof:
         agg = {}
@@ -207,6 +208,12 @@ def main():
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "alg_bytes_per_launch": round(alg_bytes),
                     "launches": nl, "avg_launch_ms": round(sec / max(nl, 1) * 1e3, 4),
                     "share_of_step": round(sec / elapsed, 3)}
+        # critic conv stack (BASELINE target: >= 40 % MFMA utilisation): every conv launch of the critic (forward, data- and
+        # weight-gradient of its 8 conv layers, incl. the HBM-bound 2-channel first layer), algorithmic flops / summed durations
+        cf = sum(v[0] for t, v in agg.items() if t.startswith("conv") and ":C" in t)
+        cs = sum(v[1] for t, v in agg.items() if t.startswith("conv") and ":C" in t)
+        critic_stack = {"tflops": round(cf / cs / 1e12, 2) if cs > 0 else None, "mfma_frac": round(cf / cs / 1e12 / peak, 4) if cs > 0 else None,
+                        "share_of_step": round(cs / elapsed, 3)}
         ops.prof = None
 
     if rank == 0:
@@ -223,7 +230,7 @@ def main():
                        "parallelism": f"dp{world}", "alg_tflop_per_sample_step": round(w_step / 1e12, 4)},
             "step_mfma_frac": round(w_step * value / world / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4),
             "losses": {k: scal[k] for k in ("critic_loss", "gp_ret", "g_loss") if k in scal},
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "critic_conv_stack": critic_stack, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, (B, S, F_, cin, nrb))

@@ -30,15 +30,25 @@ class Dist:
                 torch.cuda.set_device(self.local_rank)
             td.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
 
-    def allreduce_sum_(self, flat: torch.Tensor):
-        if self.world_size == 1:
-            return
+    def allreduce_sum_begin(self, flat: torch.Tensor):
+        """Enqueue the bucketed in-place sum of ``flat`` over the ranks (RCCL runs them on its own stream, after the work
+        already queued on the current stream) and return the handles; nothing waits yet."""
         works = []
+        if self.world_size == 1:
+            return works
         n = flat.numel()
         for off in range(0, n, self.bucket_elems):
             works.append(td.all_reduce(flat[off:min(n, off + self.bucket_elems)], op=td.ReduceOp.SUM, async_op=True))
+        return works
+
+    @staticmethod
+    def allreduce_finish(works):
+        """Make the current stream (nccl) / the host (gloo) wait for the enqueued all-reduces."""
         for w in works:
             w.wait()
+
+    def allreduce_sum_(self, flat: torch.Tensor):
+        self.allreduce_finish(self.allreduce_sum_begin(flat))
 
     def reduce_scalars(self, d: dict, mean=(), total=()):
         if self.world_size == 1:

@@ -75,7 +75,23 @@ class ParamStore:
         self.dgrad_pack = {k: o.zeros(co * 9 * ci) for k, (co, ci) in self.conv_dgrad.items()}
         self.t = 0
 
+    # A parameter update whose gradient all-reduce is still in flight on RCCL's stream can be parked here; every accessor
+    # below completes it first, so whatever needs the parameters (or the gradient buffer) next waits for it, and anything
+    # that does not (the generator's forward after a critic update) overlaps with the collective.
+    _pending = None
+
+    def defer(self, fn):
+        self.sync()
+        self._pending = fn
+
+    def sync(self):
+        fn, self._pending = self._pending, None
+        if fn is not None:
+            fn()
+
     def view(self, buf, name):
+        if self._pending is not None:
+            self.sync()
         off, n, shape = self.entries[name]
         return buf[off:off + n].view(shape)
 
@@ -87,6 +103,8 @@ class ParamStore:
 
     def w(self, name):
         """compute-precision forward pack (flat)"""
+        if self._pending is not None:
+            self.sync()
         off, n, _ = self.entries[name]
         return self.shadow[off:off + n]
 
@@ -94,6 +112,8 @@ class ParamStore:
         return self.view(self.shadow, name)
 
     def wd(self, name):
+        if self._pending is not None:
+            self.sync()
         return self.dgrad_pack[name]
 
     def refresh(self, shadow_done=False):
@@ -105,6 +125,7 @@ class ParamStore:
             o.repack(self.master(name).reshape(-1), self.dgrad_pack[name], co, ci, 1)
 
     def zero_grad(self):
+        self.sync()
         self.g.zero_()
 
     def adam_step(self, hp: HyperParams, grad_scale=1.0):
@@ -116,6 +137,7 @@ class ParamStore:
 
     def load_host(self, packed: dict):
         """packed: name -> CPU fp32 tensor of the entry's shape."""
+        self.sync()
         host = torch.zeros(self.size, dtype=torch.float32)
         for name, t in packed.items():
             off, n, shape = self.entries[name]
@@ -125,6 +147,7 @@ class ParamStore:
         self.refresh()
 
     def to_host(self, buf=None):
+        self.sync()
         h = (self.p if buf is None else buf).detach().cpu()
         return {name: h[off:off + n].view(shape).clone() for name, (off, n, shape) in self.entries.items()}
 
@@ -146,7 +169,7 @@ class NativeCritic:
         h = fine_dim
         for l, st in enumerate(self.STRIDES):
             self.convs.append(Conv(batch, h, h, self.c_pad[l], self.c_pad[l + 1], st, False,
-                                   cin_real=(nc if l == 0 and nc <= 2 else 0)))
+                                   cin_real=(nc if l == 0 and nc <= 2 else 0), net="C"))
             h //= st
         self.hf = h
         self.fc_k = h * h * self.c_pad[8]
@@ -520,11 +543,23 @@ class TrainEngine:
         i = self.SCALARS.index(name)
         return self.scal[i:i + 1]
 
-    def _allreduce_and_step(self, P):
-        # local gradients are already normalised by the GLOBAL batch, so ranks are summed, not averaged
+    def _allreduce_and_step(self, P, defer=False):
+        """Sum the flat gradient buffer over the ranks, then Adam.  Local gradients are already normalised by the GLOBAL
+        batch, so ranks are summed, not averaged.  With ``defer`` the bucketed all-reduces are only ENQUEUED (RCCL's own
+        stream) and the wait + Adam run when the parameters are next touched: after a critic update that is after the
+        following generator forward (next step's ``G(x)`` or this step's generator iteration), which hides the exchange."""
         if self.dist is not None and self.world > 1:
-            self.dist.allreduce_sum_(P.g)
-        P.adam_step(self.hp, 1.0)
+            works = self.dist.allreduce_sum_begin(P.g)
+
+            def finish():
+                self.dist.allreduce_finish(works)
+                P.adam_step(self.hp, 1.0)
+            if defer:
+                P.defer(finish)
+            else:
+                finish()
+        else:
+            P.adam_step(self.hp, 1.0)
 
     def critic_iteration(self, coarse, fine, alpha, apply_update=True):
         """wasserstein.py:27-55.  coarse/fine: native NHWC tensors; alpha: fp32 [B] on the device
@@ -543,7 +578,7 @@ class TrainEngine:
         o.gp_interp(fine, fake, alpha, self.xhat)                 # :94
         C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg)   # :40,:87-117
         if apply_update:
-            self._allreduce_and_step(C.P)                         # :52-55
+            self._allreduce_and_step(C.P, defer=True)             # :52-55 (overlaps with the next generator forward)
 
     def generator_iteration(self, coarse, fine, apply_update=True):
         """wasserstein.py:58-83: g_loss = -mean(C(G(x)))*gamma + content_lambda*L1(G(x), y)."""
@@ -688,7 +723,7 @@ class TrainEngineFS(TrainEngine):
         o.gp_interp(self.real_high, self.fake_high, alpha, self.xhat)          # :46 -> _gp(real_high, fake_high)
         C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg)
         if apply_update:
-            self._allreduce_and_step(C.P)                         # :57-60
+            self._allreduce_and_step(C.P, defer=True)             # :57-60
 
     def generator_iteration(self, coarse, fine, apply_update=True):
         """wasserstein_fs.py:63-92: g_loss = -gamma*mean C(fake_high) + content_lambda*L1(fake_low, real_low); the gradient

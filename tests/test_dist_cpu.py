@@ -40,7 +40,9 @@ def _worker(rank, world, port, outdir):
     eng, _ = _build(1, dist, global_b=2)
     xc, xf, alpha = _data(rank, rank + 1)
     metrics = eng.metrics_pass(xc, xf)          # before the update: global-batch min/max (all-reduce MIN/MAX) and means
-    ran_g = eng.train_step(xc, xf, alpha)
+    ran_g = eng.train_step(xc, xf, alpha)       # step 0: critic + generator update
+    eng.train_step(xc, xf, alpha)               # step 1: critic only; its deferred all-reduce + Adam complete in state_dict()
+    assert eng.C.P._pending is not None         # the critic update is parked behind the (next) generator forward
     scal = eng.read_scalars(ran_g)
     torch.save({"C": eng.C.state_dict(), "G": eng.G.state_dict(), "scal": scal, "metrics": metrics}, os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
@@ -52,6 +54,7 @@ def test_two_ranks_equal_single_process():
     xc, xf, alpha = _data(0, 2)
     ref_metrics = eng.metrics_pass(xc, xf)
     ran_g = eng.train_step(xc, xf, alpha)
+    eng.train_step(xc, xf, alpha)
     ref_scal = eng.read_scalars(ran_g)
     ref_c, ref_g = eng.C.state_dict(), eng.G.state_dict()
     with tempfile.TemporaryDirectory() as d:
@@ -61,12 +64,15 @@ def test_two_ranks_equal_single_process():
         r1 = torch.load(os.path.join(d, "r1.pt"))
     for k in ref_c:
         assert torch.equal(r0["C"][k], r1["C"][k]), k                       # replicas stay identical
-        assert torch.allclose(r0["C"][k], ref_c[k], rtol=0, atol=2e-6), (k, float((r0["C"][k] - ref_c[k]).abs().max()))
+        # two Adam steps: an entry whose gradient is rounding noise (|g| ~ eps) moves by up to lr per step in either
+        # direction, so single entries are bounded by 2*lr*steps and the tensors as a whole by their norm
+        assert torch.allclose(r0["C"][k], ref_c[k], rtol=0, atol=2 * 2.5e-4 * 2), (k, float((r0["C"][k] - ref_c[k]).abs().max()))
+        assert float((r0["C"][k] - ref_c[k]).norm()) <= 2e-4 * float(ref_c[k].norm()) + 1e-6, (k, float((r0["C"][k] - ref_c[k]).norm()), float(ref_c[k].norm()))
     for k in ref_g:
         assert torch.equal(r0["G"][k], r1["G"][k]), k
-        assert torch.allclose(r0["G"][k], ref_g[k], rtol=0, atol=2e-6), k
-    for k in ("critic_loss", "gp_ret", "g_loss", "content_loss", "c_real_mean"):
-        assert abs(r0["scal"][k] - ref_scal[k]) <= 1e-5 * max(1.0, abs(ref_scal[k])), (k, r0["scal"][k], ref_scal[k])
+        assert torch.allclose(r0["G"][k], ref_g[k], rtol=0, atol=0.25 * 2.5e-4), k
+    for k in ("critic_loss", "gp_ret", "g_loss", "content_loss", "c_real_mean"):   # scalars of step 1 (g_loss of step 0)
+        assert abs(r0["scal"][k] - ref_scal[k]) <= 2e-5 * max(1.0, abs(ref_scal[k])), (k, r0["scal"][k], ref_scal[k])
     for k in ("MAE", "MSE", "Wass", "MSSSIM"):          # metrics pass of the sharded batch == whole batch in one process
         assert r0["metrics"][k] == r1["metrics"][k], k
         assert abs(r0["metrics"][k] - ref_metrics[k]) <= 1e-5 * max(1.0, abs(ref_metrics[k])), (k, r0["metrics"][k], ref_metrics[k])
