@@ -716,8 +716,8 @@ __global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_
 // Halo kernel with 128-channel K-steps (16 chunks = 256-byte LDS rows).  In-kernel cycle stamps of the 64-channel
 // version show ~700-900 cycles per tap-step that do not shrink with the MFMA work (LDS store + barrier skew between
 // the two waves of a SIMD + scalar bookkeeping), against 1024 MFMA-pipe cycles: doubling the channels per step
-// doubles the MFMA work those fixed costs are amortised over.  The patch is single-buffered (83 KB) and swapped
-// at the channel-block boundary between two barriers; weights use two 32-KB slots with a register prefetch.
+// doubles the MFMA work those fixed costs are amortised over.  The patch is single-buffered (86 KB with row padding) and
+// swapped at the channel-block boundary between two barriers; weights stream by LDS-DMA into two 32-KB slots.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 #ifdef DG_STAMP
