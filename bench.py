@@ -160,8 +160,14 @@ def main():
     if args.graphs:
         eng.enable_graphs(xc, xf)
         args.no_kernel_timing = True          # per-launch events cannot be recorded inside a replayed graph
+    def complete_updates():
+        # the critic's Adam is deferred behind the next generator forward (engine.py); finish it so that exactly the work
+        # of the steps issued so far lies before the synchronisation point
+        eng.C.P.sync(); eng.G.P.sync()
+
     for s in range(args.warmup):
         eng.train_step(xc, xf, alphas[s])
+    complete_updates()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -170,6 +176,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.warmup, nsteps):
         eng.train_step(xc, xf, alphas[s])
+    complete_updates()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
