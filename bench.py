@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="diagnostic: split the `kernels` table by layer geometry (with bytes)")
     ap.add_argument("--graphs", action="store_true", help="replay the iterations as captured HIP graphs (small, launch-bound tiles)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gradient exchange goes over gloo")
@@ -173,6 +174,7 @@ def main():
     torch.cuda.synchronize()
     if not args.no_kernel_timing:
         ops.prof = []
+        ops.per_layer = args.per_layer
     t0 = time.perf_counter()
     for s in range(args.warmup, nsteps):
         eng.train_step(xc, xf, alphas[s])
@@ -196,8 +198,10 @@ def main():
         for tag, flops, nbytes, s_ev, e_ev in ops.prof:
             a = agg.setdefault(tag, [0.0, 0.0, 0, 0.0])
             a[0] += flops; a[1] += s_ev.elapsed_time(e_ev) * 1e-3; a[2] += 1; a[3] += nbytes
-        for tag, (fl, sec, n, _nb) in agg.items():
+        for tag, (fl, sec, n, nb_) in agg.items():
             kernels[tag] = {"launches": n, "seconds": round(sec, 4), "tflops": round(fl / sec / 1e12, 2) if sec > 0 else None}
+            if args.per_layer:
+                kernels[tag]["alg_tbps"] = round(nb_ / sec / 1e12, 2) if sec > 0 else None
         # dominant kernel: gg_halo128_kernel (stride-1 conv forward + stride-1 data gradient; gg_halo_kernel is its
         # 64-channel-step sibling for Cred % 128 != 0, not used at cfg2).  Only calls that were
         # served by that kernel alone (tag suffix k8) are counted, so achieved = algorithmic flops of those

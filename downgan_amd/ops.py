@@ -79,7 +79,9 @@ class HipOps:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _timed(self, tag, flops, fn, nbytes=0.0, net=""):
+    per_layer = False     # bench.py --per-layer: tag conv launches with their layer geometry
+
+    def _timed(self, tag, flops, fn, nbytes=0.0, net="", geom=""):
         """Run one launch; when profiling is on, bracket it with HIP events on the launch stream."""
         if self.prof is None:
             return fn()
@@ -87,12 +89,18 @@ class HipOps:
         s.record()
         rc = fn()
         e.record()
+        if self.per_layer and geom:
+            tag = f"{tag}:{geom}"
         if net:
             tag = f"{tag}:{net}"
         if tag.startswith(("conv_fwd", "conv_dgrad")):
             tag = f"{tag}:k{self.lib.dg_last_conv_kernels()}"   # which kernel variant(s) served the call
         self.prof.append((tag, flops, nbytes, s, e))
         return rc
+
+    @staticmethod
+    def _geom_tag(cv):
+        return f"{cv.Cin}>{cv.Cout}@{cv.H}" + ("s2" if cv.stride == 2 else "") + ("ps" if cv.pixel_shuffle else "")
 
     @staticmethod
     def conv_flops(cv):
@@ -153,7 +161,7 @@ class HipOps:
         g = self._geom(cv, pix_layout(x)[0], pix_layout(y)[0])
         e = self._epilogue(y, **ep)
         check(self._timed("conv_fwd", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_fwd(
-            C.byref(g), C.byref(e), _ptr(x), _ptr(w_fwd), _ptr(y), self._stream()), self.conv_bytes(cv, ep), cv.net), "dg_conv3x3_fwd")
+            C.byref(g), C.byref(e), _ptr(x), _ptr(w_fwd), _ptr(y), self._stream()), self.conv_bytes(cv, ep), cv.net, self._geom_tag(cv)), "dg_conv3x3_fwd")
 
     def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, **ep):
         self._act(dy); self._act(dx); self._act(w_dgrad)
@@ -163,7 +171,7 @@ class HipOps:
         g = self._geom(cv, pix_layout(dx)[0], pix_layout(dy)[0])
         e = self._epilogue(dx, **ep)
         check(self._timed("conv_dgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_dgrad(
-            C.byref(g), C.byref(e), _ptr(dy), _ptr(w_dgrad), _ptr(dx), self._stream()), self.conv_bytes(cv, ep), cv.net), "dg_conv3x3_dgrad")
+            C.byref(g), C.byref(e), _ptr(dy), _ptr(w_dgrad), _ptr(dx), self._stream()), self.conv_bytes(cv, ep), cv.net, self._geom_tag(cv)), "dg_conv3x3_dgrad")
 
     def conv_wgrad(self, cv: Conv, x, dy, dw, db=None):
         """dw += weight gradient; db (optional, fp32 [Cout]) += bias gradient = column sums of dy."""
@@ -174,7 +182,7 @@ class HipOps:
         assert tuple(dy.shape) == self.out_shape(cv), (dy.shape, cv)
         g = self._geom(cv, pix_layout(x)[0], pix_layout(dy)[0])
         check(self._timed("conv_wgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad(
-            C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), self._stream()), self.conv_bytes(cv), cv.net), "dg_conv3x3_wgrad")
+            C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), self._stream()), self.conv_bytes(cv), cv.net, self._geom_tag(cv)), "dg_conv3x3_wgrad")
 
     def colsum(self, dy, db):
         """db[c] += sum over all pixels/rows of dy[..., c]; dy is NHWC (any dtype of {fp32, compute}) or 2-D."""
