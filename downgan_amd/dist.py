@@ -10,8 +10,10 @@ from __future__ import annotations
 
 import os
 
-import torch
-import torch.distributed as td
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this pool's driver
+
+import torch  # noqa: E402
+import torch.distributed as td  # noqa: E402
 
 
 class Dist:
