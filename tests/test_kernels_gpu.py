@@ -48,8 +48,8 @@ CONVS = [
     (2, 32, 64, 128, 128, 1, False),
     (2, 48, 80, 256, 128, 2, False),    # stride-2 forward on the halo kernel: 4 parity planes x 2 channel blocks, ragged 24x40 grid
     (1, 32, 32, 128, 192, 2, False),    # ... with a partial channel tile
-    (2, 64, 48, 128, 128, 2, False),    # one reduction block: the four data-gradient classes run as one fused launch (bf16)
-    (1, 32, 48, 192, 64, 2, False),     # ... (fp32: 64 reduction channels = one block), partial channel tile
+    (2, 64, 48, 128, 128, 2, False),    # stride 2 with a single reduction-channel block (the critic's features.2 shape class)
+    (1, 32, 48, 192, 64, 2, False),     # ... and a partial channel tile
 ]
 
 
