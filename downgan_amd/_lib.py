@@ -20,7 +20,7 @@ class Epilogue(C.Structure):
                 ("r1", C.c_void_p), ("ldr1", C.c_int64), ("s1", C.c_float),
                 ("r2", C.c_void_p), ("ldr2", C.c_int64), ("s2", C.c_float),
                 ("mask", C.c_void_p), ("ldmask", C.c_int64), ("mask_slope", C.c_float),
-                ("accumulate", C.c_int)]
+                ("accumulate", C.c_int), ("mask_bits", C.c_void_p), ("out_bits", C.c_void_p)]
 
 
 class ConvGeom(C.Structure):

@@ -28,6 +28,7 @@ static thread_local int g_last_kinds = 0;
 struct GGArgs {
   const void* x; const void* w; void* y;
   const float* bias; const void* r1; const void* r2; const void* mask;
+  const void* mask_bits; void* out_bits;     // 1-bit LeakyReLU masks (u16 per lane: 4 fragments x 4 channels), see dg_epilogue
   long long ldx, ldw, ldy, ldr1, ldr2, ldmask;
   int M, Hg, Wg, Hs, Ws;
   int cch, kchunks, Cred, ntaps;
@@ -125,6 +126,13 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
   const __amdgpu_buffer_rsrc_t r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1), r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2),
                                rm = rsrc(a.mask ? a.mask : a.y, a.ldmask);
   const int ldy = (int)a.ldy, ld1 = (int)a.ldr1, ld2 = (int)a.ldr2, ldm = (int)a.ldmask;
+  // bit masks: one u16 per (pixel, 64-channel block, lane group g) holding bit 4j+e for channel 16j + 4g + e of the block
+  const int ldb = (a.Nout >> 6) * 4, bidx = ((c0 + wc * WC) >> 6) * 4 + g;
+  const bool bits_ok = WC == 64 && c0 + wc * WC < a.Nout;
+  const __amdgpu_buffer_rsrc_t rbi = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(a.mask_bits ? a.mask_bits : a.y) + pb * ldb * 2), 0, (int)DG_OOB_OFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbo = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<char*>(a.out_bits ? a.out_bits : a.y) + pb * ldb * 2), 0, (int)DG_OOB_OFF, 0x00020000);
 #pragma unroll
   for (int i = 0; i < FP; ++i) {
     const int m = p0 + wp * WP + 16 * i + l15;
@@ -132,6 +140,9 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
     const int rel = pok ? (int)(dest_pixel(m) - pb) : 0;
     unsigned oyv[FC];
     V v1[FC], v2[FC], vm[FC], va[FC];
+    const unsigned boff = (pok && bits_ok) ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF;
+    unsigned mb = 0, ob = 0;
+    if (a.mask_bits) mb = __builtin_amdgcn_raw_buffer_load_b16(rbi, boff, 0, 0);
 #pragma unroll
     for (int j = 0; j < FC; ++j) {
       const bool ok = pok && cok[j];
@@ -165,13 +176,22 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
       }
+      if (a.mask_bits) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= ((mb >> (4 * j + e)) & 1u) ? 1.f : a.mask_slope;
+      }
       if (a.accumulate) {
         IO::unpack(va[j], r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += r[e];
       }
+      if (a.out_bits) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ob |= (v[e] > 0.f ? 1u : 0u) << (4 * j + e);
+      }
       IO::store(v, rY, oyv[j]);
     }
+    if (a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, rbo, boff, 0, 0);
   }
 }
 
@@ -485,12 +505,21 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4]
   const __amdgpu_buffer_rsrc_t r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1), r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2),
                                rm = rsrc(a.mask ? a.mask : a.y, a.ldmask);
   const int ldy = (int)a.ldy, ld1 = (int)a.ldr1, ld2 = (int)a.ldr2, ldm = (int)a.ldmask;
+  const int ldb = (a.Nout >> 6) * 4, bidx = ((c0 + wc * 64) >> 6) * 4 + g;
+  const bool bits_ok = c0 + wc * 64 < a.Nout;
+  const __amdgpu_buffer_rsrc_t rbi = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(a.mask_bits ? a.mask_bits : a.y) + pb * ldb * 2), 0, (int)DG_OOB_OFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbo = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<char*>(a.out_bits ? a.out_bits : a.y) + pb * ldb * 2), 0, (int)DG_OOB_OFF, 0x00020000);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const bool pok = xok && ty0 + wp * 4 + i < a.Hg;
     const int rel = rel0 + i * rowp;
     unsigned oyv[4];
     V v1[4], v2[4], vm[4], va[4];
+    const unsigned boff = (pok && bits_ok) ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF;
+    unsigned mb = 0, ob = 0;
+    if (a.mask_bits) mb = __builtin_amdgcn_raw_buffer_load_b16(rbi, boff, 0, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool ok = pok && cok[j];
@@ -524,13 +553,22 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4]
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
       }
+      if (a.mask_bits) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= ((mb >> (4 * j + e)) & 1u) ? 1.f : a.mask_slope;
+      }
       if (a.accumulate) {
         IO::unpack(va[j], r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += r[e];
       }
+      if (a.out_bits) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ob |= (v[e] > 0.f ? 1u : 0u) << (4 * j + e);
+      }
       IO::store(v, rY, oyv[j]);
     }
+    if (a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, rbo, boff, 0, 0);
   }
 }
 
@@ -1232,6 +1270,9 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     a.r2 = ep->r2; a.ldr2 = ep->ldr2; a.s2 = ep->s2;
     a.mask = ep->mask; a.ldmask = ep->ldmask; a.mask_slope = ep->mask_slope;
     a.accumulate = ep->accumulate;
+    a.mask_bits = ep->mask_bits; a.out_bits = ep->out_bits;
+    // bit masks need 64-channel wave tiles (Nout >= 128 selects them in every dispatch path) and plain destinations
+    if ((a.mask_bits || a.out_bits) && (d->Nout < 128 || d->Nout % 64 || d->dst_ps || (a.mask_bits && a.mask))) return DG_ERR_BAD_SHAPE;
     if ((a.r1 && a.ldr1 % 4) || (a.r2 && a.ldr2 % 4) || (a.mask && a.ldmask % 4)) return DG_ERR_BAD_SHAPE;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import dataclasses
 import math
+import os
 
 import torch
 
@@ -187,6 +188,11 @@ class NativeCritic:
         o = ops
         self.acts = [o.zeros(*o.out_shape(cv)) for cv in self.convs]
         self.us = [o.zeros(*o.out_shape(cv)) for cv in self.convs]
+        # 1-bit LeakyReLU' masks beside the activations (dg_epilogue.mask_bits / out_bits): the data-gradient and
+        # tangent-forward epilogues are HBM-bound and the mask would otherwise be a full re-read of the activation.
+        # Needs 64-channel wave tiles, i.e. every conv width >= 128 (cfg2: yes; the 16-filter configs keep plain masks).
+        use_bits = os.environ.get("DG_NO_MASK_BITS") is None and all(c >= 128 and c % 64 == 0 for c in self.c_pad[1:])
+        self.act_bits = [o.zeros(*o.bits_shape(a.shape), dtype=torch.int16) for a in self.acts] if use_bits else None
         self.h1pre = o.zeros(batch, FC_HID_LD, dtype=torch.float32)
         self.h1 = o.zeros(batch, FC_HID_LD)
         self.outpre = o.zeros(batch, FC_OUT_P, dtype=torch.float32)
@@ -237,7 +243,8 @@ class NativeCritic:
         cur = x
         for l, cv in enumerate(self.convs):
             o.conv_fwd(cv, cur, P.w(f"features.{2 * l}.weight"), self.acts[l],
-                       bias=P.master("features.0.bias") if l == 0 else None, act=C_SLOPE)
+                       bias=P.master("features.0.bias") if l == 0 else None, act=C_SLOPE,
+                       out_bits=self.act_bits[l] if self.act_bits else None)
             cur = self.acts[l]
         y7 = self.acts[7].view(self.B, self.fc_k)
         self.h1pre.zero_()
@@ -273,7 +280,10 @@ class NativeCritic:
             if wgrad:   # features.0 also carries the only conv bias of the critic (critic.py:21-23)
                 o.conv_wgrad(cv, xin, self.us[l], P.grad(name).reshape(-1), db=P.grad("features.0.bias") if l == 0 else None)
             if l > 0:
-                o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask=self.acts[l - 1], mask_slope=C_SLOPE)
+                if self.act_bits:
+                    o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask_bits=self.act_bits[l - 1], mask_slope=C_SLOPE)
+                else:
+                    o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask=self.acts[l - 1], mask_slope=C_SLOPE)
             elif dx is not None:
                 o.conv_dgrad(cv, self.us[0], P.wd(name), dx)
 
@@ -303,7 +313,10 @@ class NativeCritic:
             name = f"features.{2 * l}.weight"
             o.conv_wgrad(cv, t, self.us[l], P.grad(name).reshape(-1))
             tn = self._tan[l & 1][:self.acts[l].numel()].view(self.acts[l].shape)
-            o.conv_fwd(cv, t, P.w(name), tn, mask=self.acts[l], mask_slope=C_SLOPE)
+            if self.act_bits:
+                o.conv_fwd(cv, t, P.w(name), tn, mask_bits=self.act_bits[l], mask_slope=C_SLOPE)
+            else:
+                o.conv_fwd(cv, t, P.w(name), tn, mask=self.acts[l], mask_slope=C_SLOPE)
             t = tn
         t7 = t.view(self.B, self.fc_k)
         o.linear_dw(self.uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"))

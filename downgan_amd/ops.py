@@ -123,8 +123,15 @@ class HipOps:
         return ConvGeom(dtype=self.dg, N=cv.N, H=cv.H, W=cv.W, Cin=cv.Cin, Cout=cv.Cout, stride=cv.stride,
                         cin_real=cv.cin_real, pixel_shuffle=int(cv.pixel_shuffle), ldx=ldx, ldy=ldy)
 
+    @staticmethod
+    def bits_shape(shape):
+        """Shape of the 1-bit mask tensor (int16) of an NHWC activation tensor: [N, H, W, C/64, 4]."""
+        N, H, W, Cc = shape
+        assert Cc % 64 == 0 and Cc >= 128, Cc
+        return (N, H, W, Cc // 64, 4)
+
     def _epilogue(self, out, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None, mask_slope=1.0,
-                  accumulate=False):
+                  accumulate=False, mask_bits=None, out_bits=None):
         ep = Epilogue()
         ep.bias = bias.data_ptr() if bias is not None else None
         if bias is not None:
@@ -145,6 +152,11 @@ class HipOps:
             ep.ldmask = pix_layout(mask)[0]
         ep.mask_slope = float(mask_slope)
         ep.accumulate = int(accumulate)
+        for name, t in (("mask_bits", mask_bits), ("out_bits", out_bits)):
+            if t is not None:
+                assert t.dtype == torch.int16 and t.is_cuda and t.is_contiguous() and tuple(t.shape) == self.bits_shape(out.shape), (name, t.shape, out.shape)
+                setattr(ep, name, t.data_ptr())
+        assert not (mask is not None and mask_bits is not None)
         return ep
 
     # ------------------------------------------------------------------ conv family

@@ -49,8 +49,32 @@ class EmuOps:
         assert n > 0, n
         return [d[i] for i in range(n)]
 
+    @staticmethod
+    def bits_shape(shape):
+        N, H, W, Cc = shape
+        assert Cc % 64 == 0 and Cc >= 128, Cc
+        return (N, H, W, Cc // 64, 4)
+
+    @staticmethod
+    def _bit_index(Cc):
+        """channel c -> (block, g, bit): c = 64*block + 16*j + 4*g + e, bit = 4*j + e (include/downgan_hip.h, dg_epilogue)."""
+        c = torch.arange(Cc)
+        return c // 64, (c % 16) // 4, 4 * ((c % 64) // 16) + c % 4
+
+    def _pack_bits(self, pos, bits):
+        blk, g, b = self._bit_index(pos.shape[-1])
+        words = torch.zeros(*bits.shape, dtype=torch.int32)
+        for c in range(pos.shape[-1]):
+            words[..., blk[c], g[c]] |= (pos[..., c].to(torch.int32) << int(b[c]))
+        bits.copy_(words.to(torch.int16))          # wraps bit 15 into the sign
+
+    def _unpack_bits(self, bits, Cc):
+        blk, g, b = self._bit_index(Cc)
+        w = bits.to(torch.int32) & 0xffff
+        return torch.stack([(w[..., blk[c], g[c]] >> int(b[c])) & 1 for c in range(Cc)], dim=-1).bool()
+
     def _gather_gemm(self, d, x, w, y, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None,
-                     mask_slope=1.0, accumulate=False):
+                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None):
         N = d.N
         xs = x.float()
         if d.src_ps:
@@ -94,9 +118,18 @@ class EmuOps:
             v = v * s2 + r2[sl].float()
         if mask is not None:
             v = v * _lgrad(mask[sl].float(), mask_slope)
+        if mask_bits is not None:
+            assert not d.dst_ps
+            pos = self._unpack_bits(mask_bits[sl], y.shape[-1])
+            v = v * torch.where(pos[..., :v.shape[-1]], torch.ones(()), torch.full((), float(mask_slope)))
         if accumulate:
             v = v + ysub.float()
         ysub.copy_(v.to(y.dtype))
+        if out_bits is not None:
+            assert not d.dst_ps and d.dy_mul == 1 and d.dx_mul == 1
+            full = torch.zeros(*y.shape, dtype=torch.bool)
+            full[..., :v.shape[-1]] = y[..., :v.shape[-1]].float() > 0
+            self._pack_bits(full, out_bits)
 
     def conv_fwd(self, cv: Conv, x, w_fwd, y, **ep):
         assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(y.shape) == self.out_shape(cv)

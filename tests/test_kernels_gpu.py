@@ -298,3 +298,66 @@ def test_conv_fwd_small_cin(dtype, N, H, W, co, cin_real):
         emu.conv_fwd(cv, x, w, y_ref, **ep)
         hip.conv_fwd(cv, x.cuda(), w.cuda(), y, **{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ep.items()})
         close(y, y_ref, dtype, f"im2col fwd {list(ep)}")
+
+
+# ------------------------------------------------------------------ 1-bit LeakyReLU' masks (dg_epilogue.mask_bits / out_bits)
+BITS = [
+    # N, H, W, Cin, Cout, stride, cin_real
+    (1, 32, 32, 128, 128, 1, 0),       # halo kernel
+    (2, 24, 40, 128, 256, 1, 0),       # ragged tiles, two channel tiles
+    (1, 32, 48, 128, 192, 2, 0),       # stride 2: forward on the halo kernel; data gradient = 3 halo classes + 1 per-tap class
+    (1, 64, 32, 256, 128, 2, 0),
+    (2, 32, 32, 16, 128, 1, 2),        # <= 2 real input channels: im2col forward
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", BITS)
+def test_mask_bits_forward_and_dgrad(dtype, cfg):
+    """out_bits of a forward launch == (stored activation > 0) in the documented packing; a data gradient masked by the
+    bits is bit-identical to the same launch masked by the activation tensor itself."""
+    N, H, W, ci, co, st, cr = cfg
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(5)
+    cv = Conv(N, H, W, ci, co, st, False, cin_real=cr)
+    x = rnd((N, H, W, ci), emu.tdtype, g)
+    if cr:
+        x[..., cr:] = 0
+    w = rnd((co * 9 * ci,), emu.tdtype, g, 0.1)
+    b = torch.randn(co, generator=g)
+    y = hip.zeros(*hip.out_shape(cv))
+    bits = hip.zeros(*hip.bits_shape(y.shape), dtype=torch.int16)
+    hip.conv_fwd(cv, x.cuda(), w.cuda(), y, bias=b.cuda(), act=0.2, out_bits=bits)
+    want = torch.zeros(*bits.shape, dtype=torch.int16)
+    emu._pack_bits(y.float().cpu() > 0, want)
+    assert torch.equal(bits.cpu(), want)
+    # the same forward as a masked launch (the penalty's tangent forward): bits vs the activation as the mask
+    t = rnd((N, H, W, ci), emu.tdtype, g)
+    if cr:
+        t[..., cr:] = 0
+    o1, o2 = hip.zeros(*y.shape), hip.zeros(*y.shape)
+    hip.conv_fwd(cv, t.cuda(), w.cuda(), o1, mask=y, mask_slope=0.2)
+    hip.conv_fwd(cv, t.cuda(), w.cuda(), o2, mask_bits=bits, mask_slope=0.2)
+    assert torch.equal(o1, o2)
+    # data gradient of a layer whose INPUT activation has `ci` channels: mask over dx
+    if ci >= 128:
+        act_in = rnd((N, H, W, ci), emu.tdtype, g).cuda()
+        bits_in = hip.zeros(*hip.bits_shape(act_in.shape), dtype=torch.int16)
+        packed = torch.zeros(*bits_in.shape, dtype=torch.int16)
+        emu._pack_bits(act_in.float().cpu() > 0, packed)
+        bits_in.copy_(packed)
+        dy = rnd(tuple(y.shape), emu.tdtype, g).cuda()
+        wd = rnd((co * 9 * ci,), emu.tdtype, g, 0.1).cuda()
+        d1, d2 = hip.zeros(N, H, W, ci), hip.zeros(N, H, W, ci)
+        hip.conv_dgrad(cv, dy, wd, d1, mask=act_in, mask_slope=0.2)
+        hip.conv_dgrad(cv, dy, wd, d2, mask_bits=bits_in, mask_slope=0.2)
+        assert torch.equal(d1, d2)
+
+
+def test_mask_bits_rejected_for_narrow_layers():
+    hip, emu = pair("bf16")
+    cv = Conv(1, 16, 16, 64, 64, 1, False)
+    y = hip.zeros(1, 16, 16, 64)
+    with pytest.raises((AssertionError, RuntimeError)):
+        hip.conv_fwd(cv, hip.zeros(1, 16, 16, 64), hip.zeros(64 * 9 * 64), y, act=0.2,
+                     out_bits=torch.zeros(1, 16, 16, 1, 4, dtype=torch.int16, device="cuda"))
