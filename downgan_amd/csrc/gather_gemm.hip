@@ -91,7 +91,9 @@ template <> struct Mma<float> {
 // ---- Epilogue of the row-tiled kernels (generic / fast / im2col): like halo_epilogue below, every tensor is
 // addressed through a raw buffer descriptor based at the destination pixel of the workgroup's first row plus
 // 32-bit per-lane offsets; rows past M / channels past Nout get an out-of-range offset (stores dropped).
-template <typename T, int BP, int BC, int WP, int WC>
+// LEAN: bias / activation / bit masks only (no residual, activation-mask or accumulate operands): a third of the
+// registers, for the store-bound kernels that need occupancy more than generality.
+template <typename T, int BP, int BC, int WP, int WC, bool LEAN = false>
 __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC / 16][WP / 16], int p0, int c0, int wp, int wc,
                                             int l15, int g) {
   typedef EpiIO<T> IO;
@@ -148,10 +150,10 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
       const bool ok = pok && cok[j];
       const int pix = rel + pj[j];
       oyv[j] = ok ? (unsigned)((pix * ldy + cc[j]) * ES) : DG_OOB_OFF;
-      if (a.r1) v1[j] = IO::load(r1, ok ? (unsigned)((pix * ld1 + cc[j]) * ES) : DG_OOB_OFF);
-      if (a.r2) v2[j] = IO::load(r2, ok ? (unsigned)((pix * ld2 + cc[j]) * ES) : DG_OOB_OFF);
-      if (a.mask) vm[j] = IO::load(rm, ok ? (unsigned)((pix * ldm + cc[j]) * ES) : DG_OOB_OFF);
-      if (a.accumulate) va[j] = IO::load(rY, oyv[j]);
+      if (!LEAN && a.r1) v1[j] = IO::load(r1, ok ? (unsigned)((pix * ld1 + cc[j]) * ES) : DG_OOB_OFF);
+      if (!LEAN && a.r2) v2[j] = IO::load(r2, ok ? (unsigned)((pix * ld2 + cc[j]) * ES) : DG_OOB_OFF);
+      if (!LEAN && a.mask) vm[j] = IO::load(rm, ok ? (unsigned)((pix * ldm + cc[j]) * ES) : DG_OOB_OFF);
+      if (!LEAN && a.accumulate) va[j] = IO::load(rY, oyv[j]);
     }
 #pragma unroll
     for (int j = 0; j < FC; ++j) {
@@ -161,17 +163,17 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], a.act_slope);
       }
-      if (a.r1) {
+      if (!LEAN && a.r1) {
         IO::unpack(v1[j], r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s1 + r[e];
       }
-      if (a.r2) {
+      if (!LEAN && a.r2) {
         IO::unpack(v2[j], r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
       }
-      if (a.mask) {
+      if (!LEAN && a.mask) {
         IO::unpack(vm[j], r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
@@ -180,7 +182,7 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= ((mb >> (4 * j + e)) & 1u) ? 1.f : a.mask_slope;
       }
-      if (a.accumulate) {
+      if (!LEAN && a.accumulate) {
         IO::unpack(va[j], r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += r[e];
@@ -1088,8 +1090,8 @@ static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
 // pixel are gathered straight from the 2 real channels (4/8-byte loads) instead of walking 9 taps x 16
 // padded channels, the weight tile is built once per workgroup, and each workgroup streams several
 // 128-pixel tiles.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gg_im2col_kernel(const GGArgs a, int tiles_per_block) {
+template <typename T, bool LEAN>
+__global__ __launch_bounds__(256, LEAN ? 3 : 2) void gg_im2col_kernel(const GGArgs a, int tiles_per_block) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int KCH = 32 / EPC;         // 16-B chunks per 32-element K row
   constexpr int TPC = EPC / 2;          // taps per chunk (2 channels per tap)
@@ -1174,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void gg_im2col_kernel(const GGArgs a, int t
         for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
     }
     // (staging the tile through LDS for 16-byte row stores measured 15 % slower here too)
-    gg_epilogue<T, 128, 128, 64, 64>(a, acc, p0, c0, wp, wc, l15, g);
+    gg_epilogue<T, 128, 128, 64, 64, LEAN>(a, acc, p0, c0, wp, wc, l15, g);
     __syncthreads();
   }
 }
@@ -1187,7 +1189,8 @@ static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
   if (tpb > 16) tpb = 16;
   dim3 grid((tiles + tpb - 1) / tpb, (a.Nout + 127) / 128);
   g_last_kinds |= 16;
-  hipLaunchKernelGGL((gg_im2col_kernel<T>), grid, dim3(256), 0, st, a, tpb);
+  if (!a.r1 && !a.r2 && !a.mask && !a.accumulate) hipLaunchKernelGGL((gg_im2col_kernel<T, true>), grid, dim3(256), 0, st, a, tpb);
+  else hipLaunchKernelGGL((gg_im2col_kernel<T, false>), grid, dim3(256), 0, st, a, tpb);
   return dg_check_launch();
 }
 
