@@ -198,7 +198,7 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
 }
 
 template <typename T, int BP, int BC, int WP, int WC>
-__global__ __launch_bounds__(256) void gg_kernel(const GGArgs a) {
+__global__ __launch_bounds__(256, 2) void gg_kernel(const GGArgs a) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int NPW = BP / WP;
   constexpr int FP = WP / 16, FC = WC / 16;
@@ -1084,6 +1084,165 @@ static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Halo kernel for layers with <= 16 output channels (generator conv3.2: 128 -> 2 at 1024^2; the critic's first-layer data
+// gradient in the penalty): HBM-bound, 1/8 of the MFMA work of a 128-wide tile.  The per-tap kernel re-reads every input
+// pixel 9x through L2 (4.9 ms per pass against a 1.7 ms HBM floor); here a 16x16-pixel tile keeps the (16+2)^2 patch of one
+// 64-channel block in LDS for all taps, like the wide halo kernel, and ALL nine 16x64 weight tiles of the block beside it
+// (67 KB in total, so two workgroups share a CU and one's loads overlap the other's MFMAs: no software pipeline needed).
+// 4 waves, wave = 4 tile rows x 16 channels; per block and tap two k-chunks of (1 weight + 4 patch fragment reads, 4 MFMAs).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gg_halo16_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
+  constexpr int KC = 8;                                                  // 16-byte chunks per block row (64 bf16 / 32 fp32 channels)
+  constexpr int PITCH = KC * 16 + 16;                                    // 144 B: conflict-free fragment reads at any row offset
+  constexpr int NPL = (PROWS * KC + 255) / 256;                          // 11 patch chunks per thread
+  constexpr int WROWS = 9 * 16;
+  constexpr int NWL = (WROWS * KC + 255) / 256;                          // 5 weight chunks per thread
+  extern __shared__ __attribute__((aligned(16))) char dsm16[];
+  char* const s_patch = dsm16;                    // [PROWS][PITCH]
+  char* const s_w = dsm16 + PROWS * PITCH;        // [9 taps][16 channels][PITCH]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  unsigned rest = tile;
+  const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
+  const int ty0 = (rest % tiles_y) * TH;
+  const int img = rest / tiles_y;
+  const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0,32)
+  const int sy_base = ty0 - 1 > 0 ? ty0 - 1 : 0;
+  const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
+  const char* Wb = reinterpret_cast<const char*>(a.w);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ncb = a.cch / KC, ntaps = a.ntaps;
+
+  f32x4_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int cb = 0; cb < ncb; ++cb) {
+    u32x4_t rp[NPL], rw[NWL];
+    {
+      __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int pr = r0 + 32 * i;
+        const int py = pr / PW, px = pr - py * PW;
+        const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+        const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+        const unsigned off = ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
+        rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      }
+      __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NWL; ++i) {
+        const int wr = r0 + 32 * i;                 // row = tap * 16 + channel
+        const int t = wr >> 4, n = wr & 15;
+        unsigned off = DG_OOB_OFF;
+        if (wr < WROWS && t < ntaps && n < a.Nout) {
+          const unsigned code = t < 8 ? (unsigned)((a.tap_lo >> (8 * t)) & 0xffull) : (a.tap_hi & 0xffu);
+          off = (unsigned)(((long long)n * a.ldw + (long long)(code >> 4) * a.Cred) * ES) + cc * 16;
+        }
+        rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rwd, off, 0, 0);
+      }
+    }
+    __syncthreads();                                // everybody is done with the previous block's tiles
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0 + 32 * i;
+      if (pr < PROWS) *reinterpret_cast<uint4*>(s_patch + pr * PITCH + cc * 16) = __builtin_bit_cast(uint4, rp[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int wr = r0 + 32 * i;
+      if (wr < WROWS) *reinterpret_cast<uint4*>(s_w + wr * PITCH + cc * 16) = __builtin_bit_cast(uint4, rw[i]);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntaps; ++t) {
+      const unsigned code = t < 8 ? (unsigned)((a.tap_lo >> (8 * t)) & 0xffull) : (a.tap_hi & 0xffu);
+      const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
+      const char* pb = s_patch + ((wave * 4 + 1 + dy) * PW + 1 + dx + l15) * PITCH + g * 16;
+      const char* pa = s_w + (t * 16 + l15) * PITCH + g * 16;
+#pragma unroll
+      for (int kk = 0; kk < KC / 4; ++kk) {
+        const uint4 fa = *reinterpret_cast<const uint4*>(pa + kk * 64);
+        uint4 fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + kk * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Mma<T>::run(fa, fb[i], acc[i]);
+      }
+    }
+  }
+
+  // epilogue: lane = pixel (tile row wave*4 + i, column l15), channels 4g .. 4g+3
+  typedef EpiIO<T> IO;
+  typedef typename IO::V V;
+  const int psm = a.dy_mul, psx = a.dx_mul;
+  const long long pbase = ((long long)img * a.Hd + (long long)ty0 * psm + a.dy_off) * a.Wd + (long long)tx0 * psx + a.dx_off;
+  const int cj = 4 * g;
+  const bool cok = cj < a.Nout && tx0 + l15 < a.Wg;
+  const float4 bias = (a.bias && cj < a.Nout) ? *reinterpret_cast<const float4*>(a.bias + cj) : make_float4(0.f, 0.f, 0.f, 0.f);
+  auto rsrc = [&](const void* p, long long ld) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + pbase * ld * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rY = rsrc(a.y, a.ldy);
+  const __amdgpu_buffer_rsrc_t r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1), r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2),
+                               rm = rsrc(a.mask ? a.mask : a.y, a.ldmask);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool ok = cok && ty0 + wave * 4 + i < a.Hg;
+    const int pix = (wave * 4 + i) * psm * a.Wd + l15 * psx;
+    const unsigned oy = ok ? (unsigned)((pix * (int)a.ldy + cj) * ES) : DG_OOB_OFF;
+    float v[4] = {acc[i][0] + bias.x, acc[i][1] + bias.y, acc[i][2] + bias.z, acc[i][3] + bias.w};
+    float r[4];
+    if (a.has_act) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], a.act_slope);
+    }
+    if (a.r1) {
+      IO::unpack(IO::load(r1, ok ? (unsigned)((pix * (int)a.ldr1 + cj) * ES) : DG_OOB_OFF), r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s1 + r[e];
+    }
+    if (a.r2) {
+      IO::unpack(IO::load(r2, ok ? (unsigned)((pix * (int)a.ldr2 + cj) * ES) : DG_OOB_OFF), r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
+    }
+    if (a.mask) {
+      IO::unpack(IO::load(rm, ok ? (unsigned)((pix * (int)a.ldmask + cj) * ES) : DG_OOB_OFF), r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
+    }
+    if (a.accumulate) {
+      IO::unpack(IO::load(rY, oy), r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    IO::store(v, rY, oy);
+  }
+}
+
+template <typename T>
+static int gg_launch_halo16(GGArgs& a, int N, hipStream_t st) {
+  constexpr int LDS_BYTES = (324 + 9 * 16) * 144;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return DG_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
+  a.nct = 1;
+  a.nwg = (unsigned)(tiles_x * tiles_y * N);
+  g_last_kinds |= 8;
+  hipLaunchKernelGGL((gg_halo16_kernel<T>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, tiles_x, tiles_y);
+  return dg_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // im2col path for stride-1 FORWARD layers with <= 2 real input channels (critic features.0 on the
 // 1024^2 tiles, generator conv1 with 2 covariates).  K = 9 taps x 2 channels = 18, so
 // the layer is bound by writing its output to HBM, not by MFMA: the 18 (padded to 32) K values of every
@@ -1252,6 +1411,10 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
     GGArgs b = a;
     if (regroup_taps_by_plane(b)) return gg_launch_halo128<T, true>(b, N, st);
   }
+  static const bool no_halo16 = getenv("DG_GG_NOHALO16") != nullptr;
+  if (!no_halo && !no_halo16 && a.Nout <= 16 && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && !a.dst_ps && a.cch % 8 == 0 && a.Hg >= 8 &&
+      a.Wg >= 8 && a.ntaps >= 2 && a.Hs == a.Hg && a.Ws == a.Wg && !a.mask_bits && !a.out_bits)
+    return gg_launch_halo16<T>(a, N, st);
   if (a.Nout > 64) return gg_launch_t<T, 128, 128, 64, 64>(a, st);
   if (a.Nout > 32) return gg_launch_t<T, 128, 64, 64, 32>(a, st);
   if (a.Nout > 16) return gg_launch_t<T, 128, 32, 32, 32>(a, st);
