@@ -775,8 +775,14 @@ extern "C" int dg_debug_stamps(unsigned long long* out) {
 // so every tap is a UNIT-stride shift in block coordinates.  The K loop runs over (plane, channel block) pairs; the patch
 // of a pair is the 17x17 blocks of that plane (gathered with stride 2 straight from the NHWC tensor, 256-byte rows), and
 // the pair's taps are the 1 / 2 / 2 / 4 taps that read the plane (a.tap_* are grouped by plane by the launcher).
-template <typename T, bool S2>
+// MODE 2 (CT) = layers with ONE reduction-channel block (Cin = 128) and several output-channel tiles: a 9-step tile pays its
+// prologue (exposed patch latency) and epilogue for only nine tap-steps (~800 TFLOP/s against ~1000 at 18 steps), and the
+// channel tiles of a pixel tile all read the same patch.  One workgroup therefore walks ALL channel tiles of its pixel tile:
+// the patch is loaded once, the weight stream continues across the tiles (tile-major tap-steps) and every tile ends with
+// its own epilogue and a cleared accumulator.
+template <typename T, int MODE>
 __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+  constexpr bool S2 = MODE == 1, CT = MODE == 2;
   constexpr int EPC = DT<T>::EPC;
   constexpr int ES = (int)sizeof(T);
   constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
@@ -795,8 +801,8 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
-  const int tile_c = tile % a.nct;
-  unsigned rest = tile / a.nct;
+  const int tile_c = CT ? 0 : tile % a.nct;
+  unsigned rest = CT ? tile : tile / a.nct;
   const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
   const int ty0 = (rest % tiles_y) * TH;
   const int img = rest / tiles_y;
@@ -817,7 +823,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   const int ncbr = a.cch / KC;                   // channel blocks of 128 (64 for fp32) reduction channels
   // (plane, channel block) pairs are numbered plane-major; planes hold 1, 2, 2, 4 taps starting at tap 0, 1, 3, 5
   auto plane_of = [&](int vcb) { return S2 ? (int)(vcb >= ncbr) + (int)(vcb >= 2 * ncbr) + (int)(vcb >= 3 * ncbr) : 0; };
-  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : a.ntaps; };
+  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : a.ntaps; };   // (CT: every tile has all taps)
   auto tap_code = [&](int vcb, int tap) {
     const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap;
     return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
@@ -858,7 +864,8 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   int w_dst0 = 0;
   auto dma_setup = [&](int vcb, int tap, int slot) {
     const unsigned code = tap_code(vcb, tap);
-    const long long wo = (long long)(code >> 4) * a.Cred + (vcb - plane_of(vcb) * ncbr) * KC * EPC;
+    const long long wo = CT ? (long long)(code >> 4) * a.Cred + (long long)vcb * BC * a.ldw
+                            : (long long)(code >> 4) * a.Cred + (vcb - plane_of(vcb) * ncbr) * KC * EPC;
     const unsigned long long wbase = (unsigned long long)(Wb + wo * ES);
     w_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wbase);
     w_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(wbase >> 32) & 0xffff);
@@ -893,8 +900,8 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
 
   const int wp = wave & 3, wc = wave >> 2;
   const int l15 = lane & 15, g = lane >> 4;
-  const int ncb = S2 ? 4 * ncbr : ncbr;
-  const int nsteps = ncbr * a.ntaps;
+  const int ncb = S2 ? 4 * ncbr : (CT ? (int)a.nct : ncbr);        // CT: ncbr == 1, vcb = output-channel tile
+  const int nsteps = (CT ? (int)a.nct : ncbr) * a.ntaps;
 
   const char* fa_k[4];
 #pragma unroll
@@ -956,7 +963,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
     int ntap = tap + 1, ncbn = cb;
     const int ntaps_cb = ntaps_of(cb);
     if (ntap == ntaps_cb) { ntap = 0; ncbn = cb + 1; }
-    const bool swap = ntap == 0 && more;
+    const bool swap = !CT && ntap == 0 && more;
     // a one-tap block (plane (0,0) of a stride-2 launch) has no earlier step of its own to fetch the next patch in:
     // fetched here and stored after this step's barrier (latency exposed, 1 step in 9)
     if (S2 && ntaps_cb == 1 && cb + 1 < ncb) load_patch(cb + 1);
@@ -970,7 +977,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
     read_frags(fa1, fb1, pa, pb, 3);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(tB);
-    if (tap == 1 && cb + 1 < ncb && ntaps_cb > 1) barrier_keep_patch(); else barrier_all();
+    if (!CT && tap == 1 && cb + 1 < ncb && ntaps_cb > 1) barrier_keep_patch(); else barrier_all();
     STAMP(tC);
     const bool fetch = s + 2 < nsteps;
     if (fetch) dma_setup(cbw, tapw, s & 1);
@@ -988,7 +995,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
       if (fetch) dma_piece(j);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (tap == 0 && cb + 1 < ncb && ntaps_cb > 1) load_patch(cb + 1);   // a whole channel block ahead; kept out of the next vmcnt wait
+    if (!CT && tap == 0 && cb + 1 < ncb && ntaps_cb > 1) load_patch(cb + 1);   // a whole channel block ahead; kept out of the next vmcnt wait
     __builtin_amdgcn_sched_barrier(0);
     if (swap) barrier_all();                 // publish the new patch before the next step's fragments are read
     read_frags(fa0, fb0, pa, pb, 0);         // (after the last step: a harmless read of valid LDS)
@@ -1002,6 +1009,15 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
     tE = tD;
     sAB += tB - tA; sBC += tC - tB; sCD += tD - tC; sDE += tE - tD;
 #endif
+    if constexpr (CT) {
+      if (ntap == 0) {                         // last tap of an output-channel tile: its outputs are complete
+        halo_epilogue<T>(a, acc, img, ty0, tx0, cb * BC, wp, wc, l15, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     tap = ntap; cb = ncbn;
   }
 #ifdef DG_STAMP
@@ -1011,7 +1027,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
 
   // (an LDS-staged epilogue with 16-byte row stores measured 0.8 % slower end to end: the tail is bound by the
   // chip-wide write burst, and the staging adds two barriers)
-  halo_epilogue<T>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
+  if constexpr (!CT) halo_epilogue<T>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
 #ifdef DG_STAMP
   STAMP(tX);
   if (blockIdx.x < 2 && lane == 0) {
@@ -1021,20 +1037,20 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
 #endif
 }
 
-template <typename T, bool S2>
+template <typename T, int MODE>
 static int gg_launch_halo128(GGArgs& a, int N, hipStream_t st) {
   constexpr int LDS_BYTES = 324 * 272 + 2 * 128 * 256;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo128_kernel<T, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo128_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return DG_ERR_LAUNCH;
     attr_set = true;
   }
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
   a.nct = (unsigned)((a.Nout + 127) / 128);
-  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  a.nwg = (MODE == 2 ? 1u : a.nct) * (unsigned)(tiles_x * tiles_y * N);
   g_last_kinds |= 8;
-  hipLaunchKernelGGL((gg_halo128_kernel<T, S2>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL((gg_halo128_kernel<T, MODE>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
   return dg_check_launch();
 }
 
@@ -1401,7 +1417,10 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
       a.Hs == a.Hg && a.Ws == a.Wg)
   {
     static const bool no128 = getenv("DG_GG_HALO64") != nullptr;
-    if (!no128 && a.cch % 16 == 0) return gg_launch_halo128<T, false>(a, N, st);
+    // one reduction block and 2..8 full output-channel tiles: all channel tiles of a pixel tile in one workgroup
+    static const bool no_ct = getenv("DG_GG_NOCT") != nullptr;
+    if (!no128 && !no_ct && a.cch == 16 && a.Nout % 128 == 0 && a.Nout >= 256 && a.Nout <= 1024) return gg_launch_halo128<T, 2>(a, N, st);
+    if (!no128 && a.cch % 16 == 0) return gg_launch_halo128<T, 0>(a, N, st);
     return gg_launch_halo<T>(a, N, st);
   }
   static const bool no_s2halo = getenv("DG_GG_NOS2HALO") != nullptr;
@@ -1409,7 +1428,7 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
       a.Wg >= 8 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1)
   {
     GGArgs b = a;
-    if (regroup_taps_by_plane(b)) return gg_launch_halo128<T, true>(b, N, st);
+    if (regroup_taps_by_plane(b)) return gg_launch_halo128<T, 1>(b, N, st);
   }
   static const bool no_halo16 = getenv("DG_GG_NOHALO16") != nullptr;
   if (!no_halo && !no_halo16 && a.Nout <= 16 && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && !a.dst_ps && a.cch % 8 == 0 && a.Hg >= 8 &&

@@ -48,6 +48,8 @@ CONVS = [
     (2, 32, 64, 128, 128, 1, False),
     (2, 48, 80, 256, 128, 2, False),    # stride-2 forward on the halo kernel: 4 parity planes x 2 channel blocks, ragged 24x40 grid
     (1, 32, 32, 128, 192, 2, False),    # ... with a partial channel tile
+    (1, 32, 48, 128, 256, 1, False),    # one reduction block, 2 output-channel tiles: channel tiles walked inside the workgroup
+    (1, 32, 32, 128, 512, 1, True),     # ... 4 tiles with the pixel-shuffle store (the generator's up-sampling convs)
     (2, 24, 40, 128, 16, 1, False),     # <= 16 output channels: small-N halo kernel (forward), ragged tiles
     (1, 32, 48, 16, 192, 1, False),     # ... as a data gradient (16 input channels, 3 reduction blocks)
     (1, 32, 32, 16, 64, 2, False),      # ... and its stride-2 parity classes
