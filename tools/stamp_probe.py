@@ -11,13 +11,24 @@ from downgan_amd.ops import Conv, HipOps
 
 o = HipOps("bf16")
 g = torch.Generator().manual_seed(0)
-for name, N, H, ci, co in [("G.b5 640->128@128", 16, 128, 640, 128), ("C.l6 512->1024@128", 16, 128, 512, 1024), ("G.b1 128->128@128", 16, 128, 128, 128)]:
-    cv = Conv(N, H, H, ci, co)
+CASES = [("G.b5 640->128@128", 16, 128, 640, 128, 1, "fwd"), ("C.l6 512->1024@128", 16, 128, 512, 1024, 1, "fwd"),
+         ("G.b1 128->128@128", 16, 128, 128, 128, 1, "fwd"), ("C.l1 128->128 s2 @1024 dgrad, activation mask (last class launch: 4 taps)", 2, 1024, 128, 128, 2, "dgrad"),
+         ("C.l1 dgrad, bit mask", 2, 1024, 128, 128, 2, "dgrad_bits"), ("C.l1 dgrad, no mask", 2, 1024, 128, 128, 2, "dgrad_nomask")]
+for name, N, H, ci, co, st, op in CASES:
+    cv = Conv(N, H, H, ci, co, st)
     x = torch.randn(N, H, H, ci, generator=g).to(o.tdtype).cuda()
     w = (torch.randn(co * 9 * ci, generator=g) * 0.05).to(o.tdtype).cuda()
     y = o.zeros(*o.out_shape(cv))
-    for _ in range(3):
-        o.conv_fwd(cv, x, w, y, act=0.2)
+    if op.startswith("dgrad"):
+        dy = torch.randn(*o.out_shape(cv), generator=g).to(o.tdtype).cuda()
+        dx = o.zeros(N, H, H, ci)
+        bits = torch.randint(-32768, 32767, o.bits_shape(dx.shape), dtype=torch.int16, device="cuda")
+        kw = dict(mask=x, mask_slope=0.2) if op == "dgrad" else dict(mask_bits=bits, mask_slope=0.2) if op == "dgrad_bits" else {}
+        for _ in range(3):
+            o.conv_dgrad(cv, dy, w, dx, **kw)
+    else:
+        for _ in range(3):
+            o.conv_fwd(cv, x, w, y, act=0.2)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 512)()
     o.lib.dg_debug_stamps.argtypes = [C.c_void_p]
