@@ -1100,6 +1100,202 @@ static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Four-wave halo kernel, TWO workgroups per CU.  Same tile as gg_halo128_kernel (16x16 pixels x 128 output channels) but
+// 64-channel K-steps, so patch (324 x 144 B) + two 16-KB weight slots = 78 KB and a second, independent workgroup shares
+// the CU: its tap-step loop runs while this one sits in its prologue (exposed patch latency) or in its store-bound
+// epilogue (~14k cycles per tile at ~2.2 TB/s chip-wide), which is where 9..18-step tiles lose 30-50 % of their time; and
+// the two waves of a SIMD now belong to different workgroups (no shared barrier, no lock-step).  Each wave owns 4 tile
+// rows x all 128 channels (8 x 4 accumulator fragments, 3 LDS fragment reads per 8 MFMAs instead of 4).
+// One barrier per step, at its top:  BARRIER | DMA W[s+2] -> slot s&1 | mma(k0) | read k0 of s+1 | mma(k1) | read k1 of s+1.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
+  constexpr int BC = 128, KC = 8;                                        // 8 chunks per row: 64 bf16 / 32 fp32 channels
+  constexpr int PITCH = KC * 16 + 16;                                    // 144 B patch rows
+  constexpr int WROW = KC * 16;                                          // 128 B weight rows, chunk c of row r at c ^ ((r >> 1) & 7)
+  constexpr int NPL = (PROWS * KC + 255) / 256;                          // 11 patch chunks per thread
+  constexpr int NWL = BC * KC / 256;                                     // 4 weight pieces per wave and step
+  extern __shared__ __attribute__((aligned(16))) char dsm4w[];
+  char* const s_patch = dsm4w;                    // [PROWS][PITCH]
+  char* const s_w = dsm4w + PROWS * PITCH;        // [2][BC][WROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tile_c = tile % a.nct;
+  unsigned rest = tile / a.nct;
+  const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
+  const int ty0 = (rest % tiles_y) * TH;
+  const int img = rest / tiles_y;
+  const int c0 = tile_c * BC;
+  const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0,32)
+  const int sy_base = ty0 - 1 > 0 ? ty0 - 1 : 0;
+  const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
+  const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ncb = a.cch / KC, ntaps = a.ntaps;
+  const int nsteps = ncb * ntaps;
+
+  unsigned woff[NWL];                             // DMA piece i of this wave: rows wave*32 + 8i .. +7, lane = (row, physical chunk)
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    int row = wave * 32 + i * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;
+    woff[i] = (unsigned)((long long)row * a.ldw * ES) + logical * 16;
+  }
+  auto tap_code = [&](int tap) { return tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu); };
+  u32x4_t rp[NPL];
+  auto load_patch = [&](int cb) {
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+    int r0v = r0;
+    asm volatile("" : "+v"(r0v));
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0v + 32 * i;
+      const int py = pr / PW, px = pr - py * PW;
+      const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+      const unsigned off = ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
+      rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  char* const st_base = s_patch + r0 * PITCH + cc * 16;
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0 + 32 * i;
+      if (pr < PROWS) *reinterpret_cast<uint4*>(st_base + i * 32 * PITCH) = __builtin_bit_cast(uint4, rp[i]);
+    }
+  };
+  typedef int i32x4h_t __attribute__((ext_vector_type(4)));
+  i32x4h_t w_rs;
+  int w_dst0 = 0;
+  auto dma_setup = [&](int cb, int tap, int slot) {
+    const unsigned code = tap_code(tap);
+    const long long wo = (long long)(code >> 4) * a.Cred + cb * KC * EPC;
+    const unsigned long long wbase = (unsigned long long)(Wb + wo * ES);
+    w_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wbase);
+    w_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(wbase >> 32) & 0xffff);
+    w_rs[2] = (int)DG_OOB_OFF;
+    w_rs[3] = 0x00020000;
+    w_dst0 = __builtin_amdgcn_readfirstlane(
+        (int)(unsigned long long)((__attribute__((address_space(3))) char*)(s_w + slot * (BC * WROW) + (wave * 32) * WROW)));
+  };
+  auto dma_piece = [&](int i) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(w_dst0 + i * 8 * WROW), "v"(woff[i]), "s"(w_rs) : "memory");
+  };
+  auto dma_w = [&](int cb, int tap, int slot) {
+    dma_setup(cb, tap, slot);
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) dma_piece(i);
+  };
+  auto barrier_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
+  auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); __syncthreads(); };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const char* fa_k[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) fa_k[kk] = s_w + l15 * WROW + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) * 16);
+  const char* const fb_lane = s_patch + l15 * PITCH + g * 16;
+  auto read_frags = [&](uint4 (&fa)[8], uint4 (&fb)[4], int pa, const char* pb, int kk) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] = *reinterpret_cast<const uint4*>(fa_k[kk] + pa + j * 16 * WROW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + kk * 64);
+  };
+  auto mma_rows = [&](const uint4 (&fa)[8], const uint4 (&fb)[4], int j0) {     // two weight fragments x four pixel rows
+#pragma unroll
+    for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
+  };
+  auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps) { t_ = 0; ++c_; } };
+  auto patch_ptr = [&](int tap_) -> const char* {
+    const unsigned code = tap_code(tap_);
+    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
+    return fb_lane + ((wave * 4 + 1 + dy) * PW + 1 + dx) * PITCH;
+  };
+
+  load_patch(0);
+  int cb = 0, tap = 0, cbw = 0, tapw = 0;
+  dma_w(0, 0, 0);
+  adv(cbw, tapw);
+  if (nsteps > 1) dma_w(cbw, tapw, 1);
+  adv(cbw, tapw);                    // -> W[2]
+  store_patch();
+  barrier_all();
+  // ONE fragment set (accumulators 128 + fragments 48 + patch staging 44 registers): a wave waits for its LDS reads in
+  // the open, which is what the second workgroup on the CU is there to cover.
+  uint4 fa[8], fb[4];
+  const char* pb = patch_ptr(0);
+  int pa = 0;
+  read_frags(fa, fb, pa, pb, 0);
+  bool first = true;
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    int ntap = tap + 1, ncbn = cb;
+    if (ntap == ntaps) { ntap = 0; ncbn = cb + 1; }
+    const bool swap = ntap == 0 && more;
+    const bool fetch = s + 2 < nsteps;
+    // k-block 0 (fragments read at the end of the previous step), then k-block 1: after it every wave has read all it
+    // needs of this step, so the barrier below frees slot s&1 (and, at a block end, the patch); W[s+1] has landed by then
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mma_rows(fa, fb, 2 * q);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(fa, fb, pa, pb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap == 0 && cb + 1 < ncb) load_patch(cb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mma_rows(fa, fb, 2 * q);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap == 0 && cb + 1 < ncb) barrier_keep_patch(); else barrier_all();
+    if (fetch) { dma_setup(cbw, tapw, s & 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma_piece(q);
+    }
+    adv(cbw, tapw);
+    pa = ((s + 1) & 1) * (BC * WROW);
+    pb = patch_ptr(ntap);
+    if (swap) {                      // channel-block boundary: the single-buffered patch is rewritten, then published
+      store_patch();
+      barrier_all();
+    }
+    if (more) read_frags(fa, fb, pa, pb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    tap = ntap; cb = ncbn;
+  }
+  halo_epilogue<T>(a, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[0]), img, ty0, tx0, c0, wave, 0, l15, g);
+  halo_epilogue<T>(a, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[4]), img, ty0, tx0, c0, wave, 1, l15, g);
+}
+
+template <typename T>
+static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
+  constexpr int LDS_BYTES = 324 * 144 + 2 * 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo4w_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return DG_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
+  a.nct = (unsigned)((a.Nout + 127) / 128);
+  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  g_last_kinds |= 8;
+  hipLaunchKernelGGL((gg_halo4w_kernel<T>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, tiles_x, tiles_y);
+  return dg_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Halo kernel for layers with <= 16 output channels (generator conv3.2: 128 -> 2 at 1024^2; the critic's first-layer data
 // gradient in the penalty): HBM-bound, 1/8 of the MFMA work of a 128-wide tile.  The per-tap kernel re-reads every input
 // pixel 9x through L2 (4.9 ms per pass against a 1.7 ms HBM floor); here a 16x16-pixel tile keeps the (16+2)^2 patch of one
@@ -1416,6 +1612,9 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   if (!no_halo && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 &&
       a.Hs == a.Hg && a.Ws == a.Wg)
   {
+    // default: the four-wave kernel, two workgroups per CU (measured +8-22 % over the eight-wave kernel on every layer)
+    static const bool no4w = getenv("DG_GG_NO4W") != nullptr;
+    if (!no4w && a.cch % 8 == 0) return gg_launch_halo4w<T>(a, N, st);
     static const bool no128 = getenv("DG_GG_HALO64") != nullptr;
     // one reduction block and 2..8 full output-channel tiles: all channel tiles of a pixel tile in one workgroup
     static const bool no_ct = getenv("DG_GG_NOCT") != nullptr;
