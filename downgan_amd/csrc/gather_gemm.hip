@@ -1107,7 +1107,9 @@ static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
 // the two waves of a SIMD now belong to different workgroups (no shared barrier, no lock-step).  Each wave owns 4 tile
 // rows x all 128 channels (8 x 4 accumulator fragments, 3 LDS fragment reads per 8 MFMAs instead of 4).
 // One barrier per step, at its top:  BARRIER | DMA W[s+2] -> slot s&1 | mma(k0) | read k0 of s+1 | mma(k1) | read k1 of s+1.
-template <typename T>
+// S2: stride-2 forward over the four parity planes of the input (see gg_halo128_kernel): K loop over (plane, channel block)
+// pairs with 1 / 2 / 2 / 4 taps, the plane's patch gathered with stride 2.
+template <typename T, bool S2>
 __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int tiles_x, int tiles_y) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int ES = (int)sizeof(T);
@@ -1130,12 +1132,15 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   const int img = rest / tiles_y;
   const int c0 = tile_c * BC;
   const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0,32)
-  const int sy_base = ty0 - 1 > 0 ? ty0 - 1 : 0;
+  const int sy_base = S2 ? (ty0 > 0 ? 2 * (ty0 - 1) : 0) : (ty0 - 1 > 0 ? ty0 - 1 : 0);
   const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
   const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
   const int l15 = lane & 15, g = lane >> 4;
-  const int ncb = a.cch / KC, ntaps = a.ntaps;
-  const int nsteps = ncb * ntaps;
+  const int ncbr = a.cch / KC;                    // real channel blocks
+  const int ncb = S2 ? 4 * ncbr : ncbr;           // (plane, channel block) pairs, plane-major
+  const int nsteps = ncbr * a.ntaps;
+  auto plane_of = [&](int vcb) { return S2 ? (int)(vcb >= ncbr) + (int)(vcb >= 2 * ncbr) + (int)(vcb >= 3 * ncbr) : 0; };
+  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : a.ntaps; };
 
   unsigned woff[NWL];                             // DMA piece i of this wave: rows wave*32 + 8i .. +7, lane = (row, physical chunk)
 #pragma unroll
@@ -1145,9 +1150,14 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;
     woff[i] = (unsigned)((long long)row * a.ldw * ES) + logical * 16;
   }
-  auto tap_code = [&](int tap) { return tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu); };
+  auto tap_code = [&](int vcb, int tap) {
+    const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap;
+    return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
+  };
   u32x4_t rp[NPL];
-  auto load_patch = [&](int cb) {
+  auto load_patch = [&](int vcb) {
+    const int plane = plane_of(vcb), cb = vcb - plane * ncbr;
+    const int ppy = plane >> 1, ppx = plane & 1;
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
     int r0v = r0;
     asm volatile("" : "+v"(r0v));
@@ -1155,7 +1165,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     for (int i = 0; i < NPL; ++i) {
       const int pr = r0v + 32 * i;
       const int py = pr / PW, px = pr - py * PW;
-      const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+      const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
       const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
       const unsigned off = ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
       rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
@@ -1173,9 +1183,9 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   typedef int i32x4h_t __attribute__((ext_vector_type(4)));
   i32x4h_t w_rs;
   int w_dst0 = 0;
-  auto dma_setup = [&](int cb, int tap, int slot) {
-    const unsigned code = tap_code(tap);
-    const long long wo = (long long)(code >> 4) * a.Cred + cb * KC * EPC;
+  auto dma_setup = [&](int vcb, int tap, int slot) {
+    const unsigned code = tap_code(vcb, tap);
+    const long long wo = (long long)(code >> 4) * a.Cred + (vcb - plane_of(vcb) * ncbr) * KC * EPC;
     const unsigned long long wbase = (unsigned long long)(Wb + wo * ES);
     w_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wbase);
     w_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(wbase >> 32) & 0xffff);
@@ -1218,9 +1228,9 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
 #pragma unroll
       for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
   };
-  auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps) { t_ = 0; ++c_; } };
-  auto patch_ptr = [&](int tap_) -> const char* {
-    const unsigned code = tap_code(tap_);
+  auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps_of(c_)) { t_ = 0; ++c_; } };
+  auto patch_ptr = [&](int vcb_, int tap_) -> const char* {
+    const unsigned code = tap_code(vcb_, tap_);
     const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
     return fb_lane + ((wave * 4 + 1 + dy) * PW + 1 + dx) * PITCH;
   };
@@ -1236,15 +1246,17 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   // ONE fragment set (accumulators 128 + fragments 48 + patch staging 44 registers): a wave waits for its LDS reads in
   // the open, which is what the second workgroup on the CU is there to cover.
   uint4 fa[8], fb[4];
-  const char* pb = patch_ptr(0);
+  const char* pb = patch_ptr(0, 0);
   int pa = 0;
   read_frags(fa, fb, pa, pb, 0);
   bool first = true;
   for (int s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
     int ntap = tap + 1, ncbn = cb;
-    if (ntap == ntaps) { ntap = 0; ncbn = cb + 1; }
+    const int ntaps_cb = ntaps_of(cb);
+    if (ntap == ntaps_cb) { ntap = 0; ncbn = cb + 1; }
     const bool swap = ntap == 0 && more;
+    const bool patch_now = cb + 1 < ncb && (ntaps_cb == 1 || tap == 0);     // fetch the next block's patch during its predecessor's first step
     const bool fetch = s + 2 < nsteps;
     // k-block 0 (fragments read at the end of the previous step), then k-block 1: after it every wave has read all it
     // needs of this step, so the barrier below frees slot s&1 (and, at a block end, the patch); W[s+1] has landed by then
@@ -1253,19 +1265,19 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     __builtin_amdgcn_sched_barrier(0);
     read_frags(fa, fb, pa, pb, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (tap == 0 && cb + 1 < ncb) load_patch(cb + 1);
+    if (patch_now) load_patch(cb + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) mma_rows(fa, fb, 2 * q);
     __builtin_amdgcn_sched_barrier(0);
-    if (tap == 0 && cb + 1 < ncb) barrier_keep_patch(); else barrier_all();
+    if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
     if (fetch) { dma_setup(cbw, tapw, s & 1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) dma_piece(q);
     }
     adv(cbw, tapw);
     pa = ((s + 1) & 1) * (BC * WROW);
-    pb = patch_ptr(ntap);
+    pb = patch_ptr(ncbn < ncb ? ncbn : 0, ntap);
     if (swap) {                      // channel-block boundary: the single-buffered patch is rewritten, then published
       store_patch();
       barrier_all();
@@ -1278,12 +1290,12 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   halo_epilogue<T>(a, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[4]), img, ty0, tx0, c0, wave, 1, l15, g);
 }
 
-template <typename T>
+template <typename T, bool S2>
 static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
   constexpr int LDS_BYTES = 324 * 144 + 2 * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo4w_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo4w_kernel<T, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return DG_ERR_LAUNCH;
     attr_set = true;
   }
@@ -1291,7 +1303,7 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
   a.nct = (unsigned)((a.Nout + 127) / 128);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
   g_last_kinds |= 8;
-  hipLaunchKernelGGL((gg_halo4w_kernel<T>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL((gg_halo4w_kernel<T, S2>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, tiles_x, tiles_y);
   return dg_check_launch();
 }
 
@@ -1614,7 +1626,7 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   {
     // default: the four-wave kernel, two workgroups per CU (measured +8-22 % over the eight-wave kernel on every layer)
     static const bool no4w = getenv("DG_GG_NO4W") != nullptr;
-    if (!no4w && a.cch % 8 == 0) return gg_launch_halo4w<T>(a, N, st);
+    if (!no4w && a.cch % 8 == 0) return gg_launch_halo4w<T, false>(a, N, st);
     static const bool no128 = getenv("DG_GG_HALO64") != nullptr;
     // one reduction block and 2..8 full output-channel tiles: all channel tiles of a pixel tile in one workgroup
     static const bool no_ct = getenv("DG_GG_NOCT") != nullptr;
@@ -1627,7 +1639,11 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
       a.Wg >= 8 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1)
   {
     GGArgs b = a;
-    if (regroup_taps_by_plane(b)) return gg_launch_halo128<T, 1>(b, N, st);
+    if (regroup_taps_by_plane(b)) {
+      static const bool no4w_s2 = getenv("DG_GG_NO4W") != nullptr || getenv("DG_GG_NO4WS2") != nullptr;
+      if (!no4w_s2) return gg_launch_halo4w<T, true>(b, N, st);
+      return gg_launch_halo128<T, 1>(b, N, st);
+    }
   }
   static const bool no_halo16 = getenv("DG_GG_NOHALO16") != nullptr;
   if (!no_halo && !no_halo16 && a.Nout <= 16 && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && !a.dst_ps && a.cch % 8 == 0 && a.Hg >= 8 &&
