@@ -205,8 +205,7 @@ def main():
             kernels[tag] = {"launches": n, "seconds": round(sec, 4), "tflops": round(fl / sec / 1e12, 2) if sec > 0 else None}
             if args.per_layer:
                 kernels[tag]["alg_tbps"] = round(nb_ / sec / 1e12, 2) if sec > 0 else None
-        # dominant kernel: gg_halo128_kernel (stride-1 conv forward + stride-1 data gradient; gg_halo_kernel is its
-        # 64-channel-step sibling for Cred % 128 != 0, not used at cfg2).  Only calls that were
+        # dominant kernel: gg_halo4w_kernel (conv forward of both strides + data gradients; two instantiations).  Only calls that were
         # served by that kernel alone (tag suffix k8) are counted, so achieved = algorithmic flops of those
         # launches / their summed launch durations, and launches/seconds give the average launch duration.
         halo = [t for t in agg if t.endswith(":k8")]
@@ -216,8 +215,8 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         ach = fl / sec / 1e12 if sec > 0 else 0.0
         alg_bytes = sum(agg[t][3] for t in halo) / max(nl, 1)
-        traffic, traffic_src = pmc_traffic("gg_halo128_kernel", args)
-        roofline = {"kernel": "gg_halo128_kernel (implicit-GEMM conv3x3, stride-1 forward + data-gradient)", "bound": "mfma",
+        traffic, traffic_src = pmc_traffic("gg_halo4w_kernel", args)
+        roofline = {"kernel": "gg_halo4w_kernel (implicit-GEMM conv3x3: forward, stride 1 and 2, and data gradients)", "bound": "mfma",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "alg_bytes_per_launch": round(alg_bytes),
                     "launches": nl, "avg_launch_ms": round(sec / max(nl, 1) * 1e3, 4),

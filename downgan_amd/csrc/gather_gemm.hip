@@ -1271,18 +1271,21 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     for (int q = 0; q < 4; ++q) mma_rows(fa, fb, 2 * q);
     __builtin_amdgcn_sched_barrier(0);
     if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
-    if (fetch) { dma_setup(cbw, tapw, s & 1);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dma_piece(q);
-    }
-    adv(cbw, tapw);
     pa = ((s + 1) & 1) * (BC * WROW);
     pb = patch_ptr(ncbn < ncb ? ncbn : 0, ntap);
     if (swap) {                      // channel-block boundary: the single-buffered patch is rewritten, then published
       store_patch();
       barrier_all();
     }
+    // next step's first fragments go out before the DMA pieces: the ~700 cycles a wave spends issuing those then cover
+    // the LDS read latency instead of preceding it
     if (more) read_frags(fa, fb, pa, pb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (fetch) { dma_setup(cbw, tapw, s & 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma_piece(q);
+    }
+    adv(cbw, tapw);
     __builtin_amdgcn_sched_barrier(0);
     tap = ntap; cb = ncbn;
   }
