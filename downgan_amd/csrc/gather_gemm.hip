@@ -1249,7 +1249,6 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   const char* pb = patch_ptr(0, 0);
   int pa = 0;
   read_frags(fa, fb, pa, pb, 0);
-  bool first = true;
   for (int s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
     int ntap = tap + 1, ncbn = cb;
