@@ -1404,7 +1404,6 @@ __global__ __launch_bounds__(256, 2) void gg_halo16_kernel(const GGArgs a, int t
 
   // epilogue: lane = pixel (tile row wave*4 + i, column l15), channels 4g .. 4g+3
   typedef EpiIO<T> IO;
-  typedef typename IO::V V;
   const int psm = a.dy_mul, psx = a.dx_mul;
   const long long pbase = ((long long)img * a.Hd + (long long)ty0 * psm + a.dy_off) * a.Wd + (long long)tx0 * psx + a.dx_off;
   const int cj = 4 * g;
