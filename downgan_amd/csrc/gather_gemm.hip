@@ -1622,11 +1622,13 @@ template <typename T>
 static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   static const bool no_halo = getenv("DG_GG_NOHALO") != nullptr;
   // the patch is sized for tap shifts in [-1, 1] around a unit-stride grid (stride-1 forward, all data gradients)
-  if (!no_halo && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 &&
-      a.Hs == a.Hg && a.Ws == a.Wg)
+  static const bool no4w = getenv("DG_GG_NO4W") != nullptr;
+  static const bool no4w1 = getenv("DG_GG_NO4W1TAP") != nullptr;
+  if (!no_halo && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 &&
+      (a.ntaps >= 2 || (a.ntaps == 1 && !no4w && !no4w1)) && a.Hs == a.Hg && a.Ws == a.Wg)
   {
-    // default: the four-wave kernel, two workgroups per CU (measured +8-22 % over the eight-wave kernel on every layer)
-    static const bool no4w = getenv("DG_GG_NO4W") != nullptr;
+    // default: the four-wave kernel, two workgroups per CU (measured +8-22 % over the eight-wave kernel on every layer);
+    // it also takes single-tap launches (the 1-tap parity class of a stride-2 data gradient)
     if (!no4w && a.cch % 8 == 0) return gg_launch_halo4w<T, false>(a, N, st);
     static const bool no128 = getenv("DG_GG_HALO64") != nullptr;
     // one reduction block and 2..8 full output-channel tiles: all channel tiles of a pixel tile in one workgroup
