@@ -575,184 +575,12 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4]
 }
 
 // ---------------------------------------------------------------------------------------------
-// Halo path (unit-stride gathers: stride-1 forward, every data gradient).  One workgroup = a 16x16 tile of
-// the GEMM-row grid of ONE image x 128 output channels, 8 waves (wave = 4 tile rows x 64 channels).
-// The 9 taps of a 3x3 stencil read overlapping source pixels, so instead of staging a [pixels][K-slice]
-// operand per tap (9x the bytes) the workgroup keeps the (16+2)x(16+2) source PATCH of the current
-// 64-channel block in LDS and every tap reads its fragments from the patch at a shifted row.  Only the
-// weights stream per tap-step.  Per 9 tap-steps: 41 KB patch + 144 KB weights for 2x the flops of the
-// per-tap kernel's 288 KB -> 3.1x fewer bytes through the vector-memory path per flop, and the patch of
-// the NEXT channel block has a whole 9-step window to arrive.
-template <typename T>
-__global__ __launch_bounds__(512) void gg_halo_kernel(const GGArgs a, int tiles_x, int tiles_y) {
-  constexpr int EPC = DT<T>::EPC;
-  constexpr int ES = (int)sizeof(T);
-  constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
-  constexpr int BC = 128;
-  constexpr int NPL = (PROWS * 8 + 511) / 512;                           // 6 patch chunks per thread
-  extern __shared__ __attribute__((aligned(16))) uint4 dsm[];
-  uint4* const s_patch = dsm;                   // [2][PROWS][8]
-  uint4* const s_w = dsm + 2 * PROWS * 8;       // [3][BC][8]: weights are fetched TWO tap-steps ahead
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
-  const int tile_c = tile % a.nct;
-  unsigned rest = tile / a.nct;
-  const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
-  const int ty0 = (rest % tiles_y) * TH;
-  const int img = rest / tiles_y;
-  const int c0 = tile_c * BC;
-  const int cc = tid & 7, r0 = tid >> 3;        // r0 in [0,64)
-
-  // patch rows owned by this thread: constant byte offsets relative to the workgroup base
-  const int sy_base = ty0 - 1 > 0 ? ty0 - 1 : 0;
-  unsigned poff[NPL];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int pr = r0 + 64 * i;
-    const int py = pr / PW, px = pr - py * PW;
-    const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
-    const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-    poff[i] = ok ? (unsigned)(((long long)(sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
-  }
-  unsigned woff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = r0 + 64 * i;
-    woff[i] = (c0 + row < a.Nout) ? (unsigned)((long long)row * a.ldw * ES) + cc * 16 : DG_OOB_OFF;
-  }
-  const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
-  const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
-
-  u32x4_t rp[NPL], rwa[2], rwb[2];
-  auto load_patch = [&](int cb) {
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * 8 * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, poff[i], 0, 0);
-  };
-  auto store_patch = [&](int buf) {
-    uint4* s = s_patch + buf * PROWS * 8;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const int pr = r0 + 64 * i;
-      if (pr < PROWS) s[pr * 8 + (cc ^ ((pr >> 1) & 7))] = __builtin_bit_cast(uint4, rp[i]);
-    }
-  };
-  auto load_w = [&](u32x4_t (&rw)[2], int cb, int tap) {
-    const unsigned code = tap < 8 ? (unsigned)((a.tap_lo >> (8 * tap)) & 0xffull) : (a.tap_hi & 0xffu);
-    const long long wo = (long long)(code >> 4) * a.Cred + cb * 8 * EPC;
-    __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + wo * ES), 0, (int)DG_OOB_OFF, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rwd, woff[i], 0, 0);
-  };
-  auto store_w = [&](const u32x4_t (&rw)[2], int buf) {
-    uint4* s = s_w + buf * BC * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = r0 + 64 * i;
-      s[row * 8 + (cc ^ ((row >> 1) & 7))] = __builtin_bit_cast(uint4, rw[i]);
-    }
-  };
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int wp = wave & 3, wc = wave >> 2;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int ncb = a.cch >> 3, ntaps = a.ntaps;
-  const int nsteps = ncb * ntaps;
-
-  // (cb, tap) of a tap-step, advanced incrementally
-  auto advance = [&](int& cbx, int& tapx) { if (++tapx == ntaps) { tapx = 0; ++cbx; } };
-  // Fragment reads of one K-half (kk) of tap-step (cbx, tapx) whose weights sit in ring slot wbx.
-  auto read_frags = [&](uint4 (&fa)[4], uint4 (&fb)[4], int cbx, int tapx, int wbx, int kk) {
-    const unsigned code = tapx < 8 ? (unsigned)((a.tap_lo >> (8 * tapx)) & 0xffull) : (a.tap_hi & 0xffu);
-    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
-    const uint4* sp = s_patch + (cbx & 1) * PROWS * 8;
-    const uint4* sw = s_w + wbx * BC * 8;
-    const int prow0 = (wp * 4 + 1 + dy) * PW + 1 + dx + l15;   // patch row of this lane's pixel in tile row wp*4
-    const int ch = kk * 4 + g;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = wc * 64 + 16 * j + l15;
-      fa[j] = sw[row * 8 + (ch ^ ((row >> 1) & 7))];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pr = prow0 + i * PW;
-      fb[i] = sp[pr * 8 + (ch ^ ((pr >> 1) & 7))];
-    }
-  };
-  auto mma_row = [&](const uint4 (&fa)[4], const uint4 (&fb)[4], int j) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
-  };
-  auto mma_block = [&](const uint4 (&fa)[4], const uint4 (&fb)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        Mma<T>::run(fa[j], fb[i], acc[j][i]);
-      }
-  };
-
-  // Software pipeline (weights ring of 3 LDS slots, fragments double-buffered in registers):
-  //   step s:  read F1 <- (s, kk=1) | MFMA on F0 = (s, kk=0) | read F0 <- (s+1, kk=0) | MFMA on F1
-  //            | store weights(s+2) (fetched during step s-1) | barrier
-  // so every LDS fragment read is in flight behind a 16-MFMA block, and the weights of step s+1 are
-  // already visible (stored during step s-1) when their first fragments are read before the barrier.
-  load_patch(0);
-  load_w(rwa, 0, 0);
-  store_patch(0);
-  store_w(rwa, 0);
-  int cbn = 0, tapn = 0;           // running position used for the prologue / look-ahead loads
-  advance(cbn, tapn);
-  if (nsteps > 1) { load_w(rwa, cbn, tapn); store_w(rwa, 1); }          // step 1 -> slot 1
-  int cb1 = cbn, tap1 = tapn;      // position of step s+1
-  advance(cbn, tapn);
-  if (nsteps > 2) load_w(rwa, cbn, tapn);                              // step 2 -> rwa (stored at the end of step 0)
-  advance(cbn, tapn);              // cbn/tapn = position of step s+3
-  __syncthreads();
-
-  uint4 fa0[4], fb0[4], fa1[4], fb1[4];
-  int cb = 0, tap = 0, wb = 0;     // wb = s % 3
-  read_frags(fa0, fb0, 0, 0, 0, 0);
-  // `rst` holds weights of step s+2 (fetched during step s-1); `rld` receives step s+3.
-  auto step = [&](int s, u32x4_t (&rst)[2], u32x4_t (&rld)[2]) {
-    if (s + 3 < nsteps) load_w(rld, cbn, tapn);
-    if (tap == 0 && cb + 1 < ncb) load_patch(cb + 1);
-    const int wb1 = wb == 2 ? 0 : wb + 1, wb2 = wb1 == 2 ? 0 : wb1 + 1;
-    read_frags(fa1, fb1, cb, tap, wb, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    mma_block(fa0, fb0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 1 < nsteps) read_frags(fa0, fb0, cb1, tap1, wb1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    mma_block(fa1, fb1);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < nsteps) store_w(rst, wb2);
-    if (cb + 1 < ncb && tap == (ntaps >= 2 ? ntaps - 2 : 0)) store_patch((cb + 1) & 1);
-    __syncthreads();
-    wb = wb1;
-    advance(cb, tap);
-    advance(cb1, tap1);
-    advance(cbn, tapn);
-  };
-  for (int s = 0; s < nsteps; s += 2) {
-    step(s, rwa, rwb);
-    if (s + 1 < nsteps) step(s + 1, rwb, rwa);
-  }
-
-  halo_epilogue<T>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
-}
-
+// Halo path (unit-stride gathers: stride-1 forward, every data gradient; stride-2 forward through parity planes).  One
+// workgroup = a 16x16 tile of the GEMM-row grid of ONE image x 128 output channels.  The 9 taps of a 3x3 stencil read
+// overlapping source pixels, so instead of staging a [pixels][K-slice] operand per tap (9x the bytes) the workgroup keeps
+// the (16+2)x(16+2) source PATCH of the current channel block in LDS and every tap reads its fragments from the patch at a
+// shifted row; only the weights stream per tap-step.  gg_halo128_kernel (8 waves, 128-channel steps, one workgroup per CU)
+// came first and stays behind DG_GG_NO4W; gg_halo4w_kernel (4 waves, 64-channel steps, two workgroups per CU) is the default.
 // Halo kernel with 128-channel K-steps (16 chunks = 256-byte LDS rows).  In-kernel cycle stamps of the 64-channel
 // version show ~700-900 cycles per tap-step that do not shrink with the MFMA work (LDS store + barrier skew between
 // the two waves of a SIMD + scalar bookkeeping), against 1024 MFMA-pipe cycles: doubling the channels per step
@@ -1080,23 +908,6 @@ static bool regroup_taps_by_plane(GGArgs& a) {
     if (t < 8) a.tap_lo |= (unsigned long long)out[t] << (8 * t); else a.tap_hi = out[t];
   }
   return true;
-}
-
-template <typename T>
-static int gg_launch_halo(GGArgs& a, int N, hipStream_t st) {
-  constexpr int LDS_BYTES = (2 * 324 + 3 * 128) * 8 * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return DG_ERR_LAUNCH;
-    attr_set = true;
-  }
-  const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
-  a.nct = (unsigned)((a.Nout + 127) / 128);
-  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
-  g_last_kinds |= 8;
-  hipLaunchKernelGGL((gg_halo_kernel<T>), dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
-  return dg_check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1630,12 +1441,10 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
     // default: the four-wave kernel, two workgroups per CU (measured +8-22 % over the eight-wave kernel on every layer);
     // it also takes single-tap launches (the 1-tap parity class of a stride-2 data gradient)
     if (!no4w && a.cch % 8 == 0) return gg_launch_halo4w<T, false>(a, N, st);
-    static const bool no128 = getenv("DG_GG_HALO64") != nullptr;
     // one reduction block and 2..8 full output-channel tiles: all channel tiles of a pixel tile in one workgroup
     static const bool no_ct = getenv("DG_GG_NOCT") != nullptr;
-    if (!no128 && !no_ct && a.cch == 16 && a.Nout % 128 == 0 && a.Nout >= 256 && a.Nout <= 1024) return gg_launch_halo128<T, 2>(a, N, st);
-    if (!no128 && a.cch % 16 == 0) return gg_launch_halo128<T, 0>(a, N, st);
-    return gg_launch_halo<T>(a, N, st);
+    if (!no_ct && a.cch == 16 && a.Nout % 128 == 0 && a.Nout >= 256 && a.Nout <= 1024) return gg_launch_halo128<T, 2>(a, N, st);
+    if (a.cch % 16 == 0) return gg_launch_halo128<T, 0>(a, N, st);
   }
   static const bool no_s2halo = getenv("DG_GG_NOS2HALO") != nullptr;
   if (!no_halo && !no_s2halo && a.sy_mul == 2 && a.sx_mul == 2 && !a.src_ps && a.cch % 16 == 0 && a.Nout > 64 && a.Hg >= 8 &&
