@@ -16,7 +16,10 @@
 // step k+1 are in flight while step k computes).  LDS rows are 128 B, XOR-swizzled by
 // chunk ^= (row>>1)&7 so that the 16 lanes of a ds_read_b128 group hit 16 different 16-B slots.
 // MFMA orientation: A = weights (rows = channels), B = pixels: each lane then owns 4 CONSECUTIVE
-// channels of one pixel in the accumulator, so the epilogue loads/stores 8-16 B vectors.
+// channels of one pixel per accumulator fragment.  In the 64-channel wave tiles the weight rows are staged in the
+// order perm64 (below), which makes a lane's FOUR fragments 16 consecutive channels: the epilogue then moves 16-byte
+// vectors (two stores of 8 bf16 instead of four of 4), and a wave store covers whole 128-B runs of a pixel -- measured
+// with tools/store_probe.hip: 6.1 TB/s against 4.6 TB/s (4.0 with a destination pixel stride of 2) for the 8-byte form.
 #include "dg_internal.h"
 
 #include <stdlib.h>
@@ -44,7 +47,43 @@ struct GGArgs {
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #define DG_OOB_OFF 0x80000000u   // voffset >= num_records: buffer loads return 0, buffer stores are dropped
 
+// Output-channel order of a 64-channel wave tile.  An MFMA D fragment gives lane group g rows 4g..4g+3 of 16-row block j.
+// Weight-tile row 16j + m holds channel 16*(m >> 2) + 4j + (m & 3) of the tile (the bit pairs [5:4] and [3:2] of the row
+// index swapped; an involution), so accumulator acc[j][.][e] of lane group g is channel 16g + 4j + e: 16 consecutive
+// channels per lane.  Every kernel with 64-channel wave tiles stages its weight rows through this map; the narrow tiles
+// (Nout <= 64) keep the natural order.
+__host__ __device__ constexpr int perm64(int r) { return (r & ~63) | ((r & 0x0c) << 2) | ((r >> 2) & 0x0c) | (r & 3); }
+
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+// 16-byte epilogue vectors of the permuted tiles: 8 bf16 or 4 fp32 consecutive channels
+template <typename T> struct EpiV;
+template <> struct EpiV<bf16_t> {
+  static constexpr int CPU = 8, NU = 2;            // channels per unit, units per lane (16 channels)
+  static __device__ __forceinline__ void unpack(const u32x4_t& t, float* v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(t[q] << 16); v[2 * q + 1] = __uint_as_float(t[q] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ u32x4_t pack(const float* v) {
+    u32x4_t t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = (unsigned)f32_to_bf16(v[2 * q]) | ((unsigned)f32_to_bf16(v[2 * q + 1]) << 16);
+    return t;
+  }
+};
+template <> struct EpiV<float> {
+  static constexpr int CPU = 4, NU = 4;
+  static __device__ __forceinline__ void unpack(const u32x4_t& t, float* v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(t[q]);
+  }
+  static __device__ __forceinline__ u32x4_t pack(const float* v) {
+    u32x4_t t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = __float_as_uint(v[q]);
+    return t;
+  }
+};
+struct EpiRes { __amdgpu_buffer_rsrc_t rY, r1, r2, rm, rbi, rbo; int ldy, ld1, ld2, ldm; };
 template <typename T> struct EpiIO;
 template <> struct EpiIO<bf16_t> {
   typedef u32x2_t V;
@@ -88,6 +127,69 @@ template <> struct Mma<float> {
   }
 };
 
+// ---- One pixel of a permuted 64-channel wave tile: the lane's 16 consecutive channels (fragments f0..f3 = 4 channels
+// each) at byte offset `off` of every operand tensor (an out-of-range offset drops the stores and zero-fills the loads).
+// `bias` = the lane's 16 bias values, `boff` = byte offset of the lane's 16-bit LeakyReLU' mask word.
+template <typename T, bool LEAN>
+__device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, const f32x4_t& f0, const f32x4_t& f1, const f32x4_t& f2,
+                                            const f32x4_t& f3, const float (&bias)[16], unsigned offy, unsigned off1, unsigned off2,
+                                            unsigned offm, unsigned boff) {
+  typedef EpiV<T> IO;
+  constexpr int NU = IO::NU, CPU = IO::CPU;
+  u32x4_t v1[NU], v2[NU], vm[NU], va[NU];
+  unsigned mb = 0, ob = 0;
+  if (a.mask_bits) mb = __builtin_amdgcn_raw_buffer_load_b16(R.rbi, boff, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (!LEAN && a.r1) v1[u] = __builtin_amdgcn_raw_buffer_load_b128(R.r1, off1, u * 16, 0);
+    if (!LEAN && a.r2) v2[u] = __builtin_amdgcn_raw_buffer_load_b128(R.r2, off2, u * 16, 0);
+    if (!LEAN && a.mask) vm[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rm, offm, u * 16, 0);
+    if (!LEAN && a.accumulate) va[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rY, offy, u * 16, 0);
+  }
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = f0[e] + bias[e]; v[4 + e] = f1[e] + bias[4 + e]; v[8 + e] = f2[e] + bias[8 + e]; v[12 + e] = f3[e] + bias[12 + e]; }
+  if (a.has_act) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = leaky(v[k], a.act_slope);
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    float r[CPU];
+    float* vu = v + u * CPU;
+    if (!LEAN && a.r1) {
+      IO::unpack(v1[u], r);
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) vu[e] = vu[e] * a.s1 + r[e];
+    }
+    if (!LEAN && a.r2) {
+      IO::unpack(v2[u], r);
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) vu[e] = vu[e] * a.s2 + r[e];
+    }
+    if (!LEAN && a.mask) {
+      IO::unpack(vm[u], r);
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) vu[e] *= leaky_grad(r[e], a.mask_slope);
+    }
+    if (a.mask_bits) {
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) vu[e] *= ((mb >> (u * CPU + e)) & 1u) ? 1.f : a.mask_slope;
+    }
+    if (!LEAN && a.accumulate) {
+      IO::unpack(va[u], r);
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) vu[e] += r[e];
+    }
+    if (a.out_bits) {
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) ob |= (vu[e] > 0.f ? 1u : 0u) << (u * CPU + e);
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(IO::pack(vu), R.rY, offy, u * 16, 0);
+  }
+  if (a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, boff, 0, 0);
+}
+
 // ---- Epilogue of the row-tiled kernels (generic / fast / im2col): like halo_epilogue below, every tensor is
 // addressed through a raw buffer descriptor based at the destination pixel of the workgroup's first row plus
 // 32-bit per-lane offsets; rows past M / channels past Nout get an out-of-range offset (stores dropped).
@@ -108,6 +210,40 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
     return ((long long)n * a.Hd + py) * a.Wd + px;
   };
   const long long pb = dest_pixel(p0);                 // workgroup-uniform
+  if constexpr (WC == 64) {
+    // permuted 64-channel wave tile: the lane's four fragments are the 16 consecutive channels from cb16
+    const int cb16 = c0 + wc * 64 + 16 * g;
+    const bool cok = cb16 < a.Nout;
+    float bias[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = (a.bias && cok) ? *reinterpret_cast<const float4*>(a.bias + cb16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bias[4 * q] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
+    }
+    int cc0 = cb16, pj0 = 0;
+    if (a.dst_ps) { const int q = cb16 / a.cps_dst; cc0 = cb16 - q * a.cps_dst; pj0 = (q >> 1) * a.Wd + (q & 1); }
+    auto rsrc = [&](const void* p, long long ld, int es) {
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + pb * ld * es), 0, (int)DG_OOB_OFF, 0x00020000);
+    };
+    const int ldb = (a.Nout >> 6) * 4, bidx = ((c0 + wc * 64) >> 6) * 4 + g;
+    EpiRes R;
+    R.rY = rsrc(a.y, a.ldy, ES);
+    R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
+    R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
+    R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+      const int m = p0 + wp * WP + 16 * i + l15;
+      const bool ok = m < a.M && cok;
+      const int rel = ok ? (int)(dest_pixel(m) - pb) : 0;
+      const int pix = rel + pj0;
+      epi64_pixel<T, LEAN>(a, R, acc[0][i], acc[1][i], acc[2][i], acc[3][i], bias,
+                           ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
+                           ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
+                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF);
+    }
+    return;
+  }
   int cc[FC], pj[FC];
   bool cok[FC];
   float4 bias[FC];
@@ -254,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(const GGArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < CR; ++i) {
-      const int row = r0 + 32 * i, n = c0 + row;
+      const int row = r0 + 32 * i, n = c0 + (WC == 64 ? perm64(row) : row);
       const bool ok = kok && row < BC && n < a.Nout;
       const long long woff = (long long)n * a.ldw + (long long)ws * a.Cred + c8 * EPC;
       uint4 v = *reinterpret_cast<const uint4*>(Wt + (ok ? woff : 0ll));
@@ -378,8 +514,8 @@ __global__ __launch_bounds__(256, 2) void gg_fast_kernel(const GGArgs a) {
   unsigned woff[CR];
 #pragma unroll
   for (int i = 0; i < CR; ++i) {
-    const int row = r0 + 32 * i;
-    woff[i] = (row < BC && c0 + row < a.Nout) ? (unsigned)((long long)row * a.ldw * ES) + cc * 16 : DG_OOB_OFF;
+    const int row = r0 + 32 * i, prow = WC == 64 ? perm64(row) : row;     // LDS row `row` holds output channel c0 + prow
+    woff[i] = (row < BC && c0 + prow < a.Nout) ? (unsigned)((long long)prow * a.ldw * ES) + cc * 16 : DG_OOB_OFF;
   }
   const char* Xb = reinterpret_cast<const char*>(a.x) + pbase * a.ldx * ES;
   const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
@@ -477,8 +613,6 @@ __global__ __launch_bounds__(256, 2) void gg_fast_kernel(const GGArgs a) {
 template <typename T>
 __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4][4], int img, int ty0, int tx0, int c0, int wp,
                                               int wc, int l15, int g) {
-  typedef EpiIO<T> IO;
-  typedef typename IO::V V;
   constexpr int ES = (int)sizeof(T);
   const int psm = a.dst_ps ? 2 : a.dy_mul, psx = a.dst_ps ? 2 : a.dx_mul;
   const int oy = a.dst_ps ? 0 : a.dy_off, ox = a.dst_ps ? 0 : a.dx_off;
@@ -486,91 +620,35 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4]
   const long long pb = ((long long)img * a.Hd + (long long)ty0 * psm + oy) * a.Wd + (long long)tx0 * psx + ox;
   const int rel0 = (wp * 4) * psm * a.Wd + l15 * psx;
   const int rowp = psm * a.Wd;
-  int cc[4], pj[4];
-  bool cok[4];
-  float4 bias[4];
+  // permuted wave tile (perm64): the lane's four channel fragments are the 16 consecutive channels from cb16
+  const int cb16 = c0 + wc * 64 + 16 * g;
+  const bool cok = cb16 < a.Nout && tx0 + l15 < a.Wg;
+  float bias[16];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int cj = c0 + wc * 64 + 16 * j + 4 * g;
-    cok[j] = cj < a.Nout;
-    bias[j] = (a.bias && cok[j]) ? *reinterpret_cast<const float4*>(a.bias + cj) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.dst_ps) {
-      const int q = cj / a.cps_dst;
-      cc[j] = cj - q * a.cps_dst; pj[j] = (q >> 1) * a.Wd + (q & 1);
-    } else { cc[j] = cj; pj[j] = 0; }
+  for (int q = 0; q < 4; ++q) {
+    const float4 b4 = (a.bias && cb16 < a.Nout) ? *reinterpret_cast<const float4*>(a.bias + cb16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bias[4 * q] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
   }
-  const bool xok = tx0 + l15 < a.Wg;
-  auto rsrc = [&](const void* p, long long ld) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + pb * ld * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+  int cc0 = cb16, pj0 = 0;
+  if (a.dst_ps) { const int q = cb16 / a.cps_dst; cc0 = cb16 - q * a.cps_dst; pj0 = (q >> 1) * a.Wd + (q & 1); }
+  auto rsrc = [&](const void* p, long long ld, int es) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + pb * ld * es), 0, (int)DG_OOB_OFF, 0x00020000);
   };
-  const __amdgpu_buffer_rsrc_t rY = rsrc(a.y, a.ldy);
-  const __amdgpu_buffer_rsrc_t r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1), r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2),
-                               rm = rsrc(a.mask ? a.mask : a.y, a.ldmask);
-  const int ldy = (int)a.ldy, ld1 = (int)a.ldr1, ld2 = (int)a.ldr2, ldm = (int)a.ldmask;
   const int ldb = (a.Nout >> 6) * 4, bidx = ((c0 + wc * 64) >> 6) * 4 + g;
-  const bool bits_ok = c0 + wc * 64 < a.Nout;
-  const __amdgpu_buffer_rsrc_t rbi = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const char*>(a.mask_bits ? a.mask_bits : a.y) + pb * ldb * 2), 0, (int)DG_OOB_OFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rbo = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<char*>(a.out_bits ? a.out_bits : a.y) + pb * ldb * 2), 0, (int)DG_OOB_OFF, 0x00020000);
+  EpiRes R;
+  R.rY = rsrc(a.y, a.ldy, ES);
+  R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
+  R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
+  R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const bool pok = xok && ty0 + wp * 4 + i < a.Hg;
+    const bool ok = cok && ty0 + wp * 4 + i < a.Hg;
     const int rel = rel0 + i * rowp;
-    unsigned oyv[4];
-    V v1[4], v2[4], vm[4], va[4];
-    const unsigned boff = (pok && bits_ok) ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF;
-    unsigned mb = 0, ob = 0;
-    if (a.mask_bits) mb = __builtin_amdgcn_raw_buffer_load_b16(rbi, boff, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool ok = pok && cok[j];
-      const int pix = rel + pj[j];
-      oyv[j] = ok ? (unsigned)((pix * ldy + cc[j]) * ES) : DG_OOB_OFF;
-      if (a.r1) v1[j] = IO::load(r1, ok ? (unsigned)((pix * ld1 + cc[j]) * ES) : DG_OOB_OFF);
-      if (a.r2) v2[j] = IO::load(r2, ok ? (unsigned)((pix * ld2 + cc[j]) * ES) : DG_OOB_OFF);
-      if (a.mask) vm[j] = IO::load(rm, ok ? (unsigned)((pix * ldm + cc[j]) * ES) : DG_OOB_OFF);
-      if (a.accumulate) va[j] = IO::load(rY, oyv[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4] = {acc[j][i][0] + bias[j].x, acc[j][i][1] + bias[j].y, acc[j][i][2] + bias[j].z, acc[j][i][3] + bias[j].w};
-      float r[4];
-      if (a.has_act) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], a.act_slope);
-      }
-      if (a.r1) {
-        IO::unpack(v1[j], r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s1 + r[e];
-      }
-      if (a.r2) {
-        IO::unpack(v2[j], r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
-      }
-      if (a.mask) {
-        IO::unpack(vm[j], r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
-      }
-      if (a.mask_bits) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= ((mb >> (4 * j + e)) & 1u) ? 1.f : a.mask_slope;
-      }
-      if (a.accumulate) {
-        IO::unpack(va[j], r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += r[e];
-      }
-      if (a.out_bits) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ob |= (v[e] > 0.f ? 1u : 0u) << (4 * j + e);
-      }
-      IO::store(v, rY, oyv[j]);
-    }
-    if (a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, rbo, boff, 0, 0);
+    const int pix = rel + pj0;
+    epi64_pixel<T, false>(a, R, acc[0][i], acc[1][i], acc[2][i], acc[3][i], bias,
+                          ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
+                          ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
+                          ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF);
   }
 }
 
@@ -641,7 +719,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   unsigned woff[NWL];                            // lane's source offset for DMA piece i: row r0+32i, chunk cc ^ (r0 & 15)
 #pragma unroll
   for (int i = 0; i < NWL; ++i) {
-    int row = r0 + 32 * i;
+    int row = perm64(r0 + 32 * i);                   // LDS row r0+32i holds output channel c0 + perm64(row)
     if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;   // rows past Cout: any valid row (their outputs are never stored)
     woff[i] = (unsigned)((long long)row * a.ldw * ES) + ((cc ^ (r0 & 15)) * 16);
   }
@@ -958,6 +1036,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   for (int i = 0; i < NWL; ++i) {
     int row = wave * 32 + i * 8 + (lane >> 3);
     const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    row = perm64(row);                              // LDS row holds output channel c0 + perm64(row)
     if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;
     woff[i] = (unsigned)((long long)row * a.ldw * ES) + logical * 16;
   }
@@ -1306,11 +1385,12 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void gg_im2col_kernel(const GGAr
   for (int i = 0; i < NCH; ++i) {
     const int e = tid + 256 * i, row = e / KCH, col = e % KCH;
     unsigned w[4] = {0u, 0u, 0u, 0u};
-    if (c0 + row < a.Nout) {
+    const int n = c0 + perm64(row);                 // 64-channel wave tiles: permuted channel order
+    if (n < a.Nout) {
 #pragma unroll
       for (int tt = 0; tt < TPC; ++tt) {
         const int tp = col * TPC + tt;
-        if (tp < 9) load_pair(Wt + ((long long)(c0 + row) * 9 + tp) * a.Cred, w + tt * (4 / TPC));
+        if (tp < 9) load_pair(Wt + ((long long)n * 9 + tp) * a.Cred, w + tt * (4 / TPC));
       }
     }
     sW[row * KCH + (col ^ swz(row))] = make_uint4(w[0], w[1], w[2], w[3]);

@@ -54,8 +54,8 @@ typedef struct dg_epilogue {
   const void* mask; int64_t ldmask; float mask_slope;
   int accumulate;
   /* 1-bit form of the LeakyReLU' mask (16x fewer bytes than re-reading the activation; the critic's data-gradient
-   * epilogues are HBM-bound on it): a tensor [pixel][Cout/64][4] of uint16, word (block, g) holding bit 4j+e for channel
-   * 64*block + 16j + 4g + e.  mask_bits: multiply by (bit ? 1 : mask_slope) (instead of `mask`); out_bits: written by this
+   * epilogues are HBM-bound on it): a tensor [pixel][Cout/64][4] of uint16, bit b of word (block, g) belonging to channel
+   * 64*block + 16g + b -- a little-endian bit string over the channels of a pixel.  mask_bits: multiply by (bit ? 1 : mask_slope) (instead of `mask`); out_bits: written by this
    * launch as (stored value > 0).  Both need Cout % 64 == 0, Cout >= 128 and no pixel shuffle. */
   const void* mask_bits;
   void* out_bits;

@@ -57,9 +57,10 @@ class EmuOps:
 
     @staticmethod
     def _bit_index(Cc):
-        """channel c -> (block, g, bit): c = 64*block + 16*j + 4*g + e, bit = 4*j + e (include/downgan_hip.h, dg_epilogue)."""
+        """channel c -> (block, word, bit): c = 64*block + 16*word + bit, i.e. a plain little-endian bit string over the
+        channels of a pixel (include/downgan_hip.h, dg_epilogue)."""
         c = torch.arange(Cc)
-        return c // 64, (c % 16) // 4, 4 * ((c % 64) // 16) + c % 4
+        return c // 64, (c % 64) // 16, c % 16
 
     def _pack_bits(self, pos, bits):
         blk, g, b = self._bit_index(pos.shape[-1])
