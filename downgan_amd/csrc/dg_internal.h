@@ -16,13 +16,15 @@ template <> struct DT<float> { static constexpr int EPC = 4; static constexpr in
 template <> struct DT<bf16_t> { static constexpr int EPC = 8; static constexpr int id = DG_BF16; };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
-// round-to-nearest-even; NaN stays NaN (the plain integer trick maps some NaNs to inf/0)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// round-to-nearest-even on the gfx950 converter (v_cvt_pk_bf16_f32: two values per instruction; the integer trick costs
+// ~7 VALU operations per value, which made the store-bound epilogues VALU-bound)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 __device__ __forceinline__ float ld_elem(const float* p) { return *p; }
 __device__ __forceinline__ float ld_elem(const bf16_t* p) { return bf16_to_f32(*p); }
@@ -44,8 +46,8 @@ __device__ __forceinline__ void st4(float* p, const float* v) {
 }
 __device__ __forceinline__ void st4(bf16_t* p, const float* v) {
   uint2 t;
-  t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-  t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+  t.x = pack_bf16x2(v[0], v[1]);
+  t.y = pack_bf16x2(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = t;
 }
 

@@ -66,7 +66,7 @@ template <> struct EpiV<bf16_t> {
   static __device__ __forceinline__ u32x4_t pack(const float* v) {
     u32x4_t t;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = (unsigned)f32_to_bf16(v[2 * q]) | ((unsigned)f32_to_bf16(v[2 * q + 1]) << 16);
+    for (int q = 0; q < 4; ++q) t[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
     return t;
   }
 };
@@ -90,8 +90,8 @@ template <> struct EpiIO<bf16_t> {
   static __device__ __forceinline__ V load(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
   static __device__ __forceinline__ void store(const float* v, __amdgpu_buffer_rsrc_t r, unsigned off) {
     V t;
-    t[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-    t[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    t[0] = pack_bf16x2(v[0], v[1]);
+    t[1] = pack_bf16x2(v[2], v[3]);
     __builtin_amdgcn_raw_buffer_store_b64(t, r, off, 0, 0);
   }
   static __device__ __forceinline__ void unpack(const V& t, float* v) {
@@ -129,16 +129,24 @@ template <> struct Mma<float> {
 
 // ---- One pixel of a permuted 64-channel wave tile: the lane's 16 consecutive channels (fragments f0..f3 = 4 channels
 // each) at byte offset `off` of every operand tensor (an out-of-range offset drops the stores and zero-fills the loads).
-// `bias` = the lane's 16 bias values, `boff` = byte offset of the lane's 16-bit LeakyReLU' mask word.
+// `bias` = the lane's 16 bias values, `boff` = byte offset of the lane's 16-bit LeakyReLU' mask word, `mb` = that word of
+// mask_bits, loaded by the caller with epi64_bits BEFORE it stores anything: memory operations retire in order, so a load
+// issued behind a store waits for the store's round trip to memory.
+template <bool LEAN>
+__device__ __forceinline__ unsigned epi64_bits(const GGArgs& a, const EpiRes& R, unsigned boff) {
+  if (LEAN || a.mask_bits) return __builtin_amdgcn_raw_buffer_load_b16(R.rbi, (LEAN && !a.mask_bits) ? DG_OOB_OFF : boff, 0, 0);
+  return 0u;
+}
 template <typename T, bool LEAN>
 __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, const f32x4_t& f0, const f32x4_t& f1, const f32x4_t& f2,
                                             const f32x4_t& f3, const float (&bias)[16], unsigned offy, unsigned off1, unsigned off2,
-                                            unsigned offm, unsigned boff) {
+                                            unsigned offm, unsigned boff, unsigned mb) {
   typedef EpiV<T> IO;
   constexpr int NU = IO::NU, CPU = IO::CPU;
   u32x4_t v1[NU], v2[NU], vm[NU], va[NU];
-  unsigned mb = 0, ob = 0;
-  if (a.mask_bits) mb = __builtin_amdgcn_raw_buffer_load_b16(R.rbi, boff, 0, 0);
+  unsigned ob = 0;
+  // LEAN runs inside a tile loop whose memory operations must be unconditional (see gg_im2col_kernel): absent bit-mask
+  // operands become out-of-range offsets (the load returns 0, the store is dropped)
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     if (!LEAN && a.r1) v1[u] = __builtin_amdgcn_raw_buffer_load_b128(R.r1, off1, u * 16, 0);
@@ -149,9 +157,15 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
   float v[16];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { v[e] = f0[e] + bias[e]; v[4 + e] = f1[e] + bias[4 + e]; v[8 + e] = f2[e] + bias[8 + e]; v[12 + e] = f3[e] + bias[12 + e]; }
+  // (pure-ALU parts may sit behind uniform branches: only the memory operations have to be unconditional)
   if (a.has_act) {
+    if (a.act_slope >= 0.f && a.act_slope <= 1.f) {          // max(v, v * slope) == leaky(v) for slopes in [0, 1]: 2 operations, not 3
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = leaky(v[k], a.act_slope);
+      for (int k = 0; k < 16; ++k) v[k] = __builtin_fmaxf(v[k], v[k] * a.act_slope);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = leaky(v[k], a.act_slope);
+    }
   }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -187,7 +201,7 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
     }
     __builtin_amdgcn_raw_buffer_store_b128(IO::pack(vu), R.rY, offy, u * 16, 0);
   }
-  if (a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, boff, 0, 0);
+  if (LEAN || a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, (LEAN && !a.out_bits) ? DG_OOB_OFF : boff, 0, 0);
 }
 
 // ---- Epilogue of the row-tiled kernels (generic / fast / im2col): like halo_epilogue below, every tensor is
@@ -231,16 +245,24 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
     R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
     R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
     R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
+    int relv[FP];
+    bool okv[FP];
+    unsigned mbv[FP];
 #pragma unroll
     for (int i = 0; i < FP; ++i) {
       const int m = p0 + wp * WP + 16 * i + l15;
-      const bool ok = m < a.M && cok;
-      const int rel = ok ? (int)(dest_pixel(m) - pb) : 0;
-      const int pix = rel + pj0;
+      okv[i] = m < a.M && cok;
+      relv[i] = okv[i] ? (int)(dest_pixel(m) - pb) : 0;
+      mbv[i] = epi64_bits<LEAN>(a, R, okv[i] ? (unsigned)((relv[i] * ldb + bidx) * 2) : DG_OOB_OFF);
+    }
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+      const bool ok = okv[i];
+      const int rel = relv[i], pix = rel + pj0;
       epi64_pixel<T, LEAN>(a, R, acc[0][i], acc[1][i], acc[2][i], acc[3][i], bias,
                            ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
                            ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
-                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF);
+                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i]);
     }
     return;
   }
@@ -610,8 +632,8 @@ __global__ __launch_bounds__(256, 2) void gg_fast_kernel(const GGArgs a) {
 // (one multiply-add per fragment and tensor instead of 64-bit index arithmetic), and out-of-tile / out-of-range
 // fragments get an out-of-range offset: the hardware drops those stores and returns zeros for those loads, so the
 // epilogue has no divergent branches.
-template <typename T>
-__device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4][4], int img, int ty0, int tx0, int c0, int wp,
+template <typename T, int NH>
+__device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 * NH][4], int img, int ty0, int tx0, int c0, int wp,
                                               int wc, int l15, int g) {
   constexpr int ES = (int)sizeof(T);
   const int psm = a.dst_ps ? 2 : a.dy_mul, psx = a.dst_ps ? 2 : a.dx_mul;
@@ -620,35 +642,51 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4]
   const long long pb = ((long long)img * a.Hd + (long long)ty0 * psm + oy) * a.Wd + (long long)tx0 * psx + ox;
   const int rel0 = (wp * 4) * psm * a.Wd + l15 * psx;
   const int rowp = psm * a.Wd;
-  // permuted wave tile (perm64): the lane's four channel fragments are the 16 consecutive channels from cb16
-  const int cb16 = c0 + wc * 64 + 16 * g;
-  const bool cok = cb16 < a.Nout && tx0 + l15 < a.Wg;
-  float bias[16];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 b4 = (a.bias && cb16 < a.Nout) ? *reinterpret_cast<const float4*>(a.bias + cb16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    bias[4 * q] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
-  }
-  int cc0 = cb16, pj0 = 0;
-  if (a.dst_ps) { const int q = cb16 / a.cps_dst; cc0 = cb16 - q * a.cps_dst; pj0 = (q >> 1) * a.Wd + (q & 1); }
   auto rsrc = [&](const void* p, long long ld, int es) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + pb * ld * es), 0, (int)DG_OOB_OFF, 0x00020000);
   };
-  const int ldb = (a.Nout >> 6) * 4, bidx = ((c0 + wc * 64) >> 6) * 4 + g;
+  const int ldb = (a.Nout >> 6) * 4;
   EpiRes R;
   R.rY = rsrc(a.y, a.ldy, ES);
   R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
   R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
   R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
+  const bool xok = tx0 + l15 < a.Wg;
+  // every mask word of the wave's tile first (NH halves x 4 rows), before the first store
+  unsigned mbv[NH][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bool ok = cok && ty0 + wp * 4 + i < a.Hg;
-    const int rel = rel0 + i * rowp;
-    const int pix = rel + pj0;
-    epi64_pixel<T, false>(a, R, acc[0][i], acc[1][i], acc[2][i], acc[3][i], bias,
-                          ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
-                          ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
-                          ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF);
+  for (int h = 0; h < NH; ++h) {
+    const int cb64 = c0 + (wc + h) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = xok && cb64 + 16 * g < a.Nout && ty0 + wp * 4 + i < a.Hg;
+      mbv[h][i] = epi64_bits<false>(a, R, ok ? (unsigned)(((rel0 + i * rowp) * ldb + (cb64 >> 6) * 4 + g) * 2) : DG_OOB_OFF);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    // permuted wave tile (perm64): the lane's four channel fragments are the 16 consecutive channels from cb16
+    const int cb16 = c0 + (wc + h) * 64 + 16 * g;
+    const bool cok = cb16 < a.Nout && xok;
+    float bias[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = (a.bias && cb16 < a.Nout) ? *reinterpret_cast<const float4*>(a.bias + cb16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bias[4 * q] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
+    }
+    int cc0 = cb16, pj0 = 0;
+    if (a.dst_ps) { const int q = cb16 / a.cps_dst; cc0 = cb16 - q * a.cps_dst; pj0 = (q >> 1) * a.Wd + (q & 1); }
+    const int bidx = ((c0 + (wc + h) * 64) >> 6) * 4 + g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = cok && ty0 + wp * 4 + i < a.Hg;
+      const int rel = rel0 + i * rowp;
+      const int pix = rel + pj0;
+      epi64_pixel<T, false>(a, R, acc[4 * h][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i], bias,
+                            ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
+                            ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
+                            ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[h][i]);
+    }
   }
 }
 
@@ -917,7 +955,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
 #endif
     if constexpr (CT) {
       if (ntap == 0) {                         // last tap of an output-channel tile: its outputs are complete
-        halo_epilogue<T>(a, acc, img, ty0, tx0, cb * BC, wp, wc, l15, g);
+        halo_epilogue<T, 1>(a, acc, img, ty0, tx0, cb * BC, wp, wc, l15, g);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -933,7 +971,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
 
   // (an LDS-staged epilogue with 16-byte row stores measured 0.8 % slower end to end: the tail is bound by the
   // chip-wide write burst, and the staging adds two barriers)
-  if constexpr (!CT) halo_epilogue<T>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
+  if constexpr (!CT) halo_epilogue<T, 1>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
 #ifdef DG_STAMP
   STAMP(tX);
   if (blockIdx.x < 2 && lane == 0) {
@@ -1178,8 +1216,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     __builtin_amdgcn_sched_barrier(0);
     tap = ntap; cb = ncbn;
   }
-  halo_epilogue<T>(a, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[0]), img, ty0, tx0, c0, wave, 0, l15, g);
-  halo_epilogue<T>(a, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[4]), img, ty0, tx0, c0, wave, 1, l15, g);
+  halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0, wave, 0, l15, g);
 }
 
 template <typename T, bool S2>
@@ -1397,41 +1434,92 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void gg_im2col_kernel(const GGAr
   }
   const int wp = wave & 1, wc = wave >> 1;
   const int l15 = lane & 15, g = lane >> 4;
+  constexpr int ES = (int)sizeof(T);
+  // Everything below is branch-free per tile (buffer loads / stores with out-of-range offsets for padding, tile ends and
+  // channel tails): the compiler can then count the outstanding operations and the LDS write of the next tile's gathered
+  // rows waits for the gather loads only (s_waitcnt vmcnt(#stores issued after them)), not for this tile's stores to
+  // reach memory -- with per-load branches it fell back to vmcnt(0) at the loop head, i.e. one store round trip per tile.
+  // forward, stride 1, plain destination: GEMM row m is both the source and the destination pixel index
+  const int col = tid % KCH, row0 = tid / KCH;                   // this thread's K chunk; rows row0 + (256 / KCH) * i
+  int tap_rel[TPC];                                              // source pixel shift of the chunk's taps
+  int tap_dy[TPC], tap_dx[TPC];
+#pragma unroll
+  for (int tt = 0; tt < TPC; ++tt) {
+    const int tp = col * TPC + tt;
+    tap_dy[tt] = tp < 9 ? tp / 3 - 1 : 4;                        // 4: never inside the image
+    tap_dx[tt] = tp < 9 ? tp % 3 - 1 : 0;
+    tap_rel[tt] = tap_dy[tt] * a.Ws + tap_dx[tt];
+  }
+  const int cb16 = c0 + wc * 64 + 16 * g;
+  const bool cok = cb16 < a.Nout;
+  float bias[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 b4 = (a.bias && cok) ? *reinterpret_cast<const float4*>(a.bias + cb16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bias[4 * q] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
+  }
+  const int ldb = (a.Nout >> 6) * 4, bidx = ((c0 + wc * 64) >> 6) * 4 + g;
   // the im2col rows of the NEXT tile are gathered into registers while the current tile's MFMAs and (long) store epilogue
   // run: the 4/8-byte gathers are latency-bound and nothing else would hide them (one barrier pair per tile)
   unsigned gw[NCH][4];
-  auto gather = [&](int p0) {
+  auto gather = [&](int p0, bool live) {
+    long long pbase = (long long)p0 - a.Ws - 1;
+    if (pbase < 0) pbase = 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) + pbase * a.ldx * ES), 0,
+                                                                      (int)DG_OOB_OFF, 0x00020000);
+    const int mrel = (int)(p0 - pbase);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int e = tid + 256 * i, row = e / KCH, col = e % KCH;
-      const int m = p0 + row;
+      const int row = row0 + (256 / KCH) * i;
+      const unsigned m = (unsigned)(p0 + row);
+      const unsigned tq = m / (unsigned)a.Wg;
+      const int gx = (int)(m - tq * (unsigned)a.Wg), gy = (int)(tq % (unsigned)a.Hg);
+      const bool mok = live & (m < (unsigned)a.M);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) gw[i][q] = 0u;
-      if (m < a.M) {
-        const int gx = m % a.Wg, tq = m / a.Wg;
-        const int gy = tq % a.Hg, n = tq / a.Hg;
-#pragma unroll
-        for (int tt = 0; tt < TPC; ++tt) {
-          const int tp = col * TPC + tt;
-          const int sy = gy + tp / 3 - 1, sx = gx + tp % 3 - 1;
-          if (tp < 9 && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws)
-            load_pair(X + ((long long)(n * a.Hs + sy) * a.Ws + sx) * a.ldx, gw[i] + tt * (4 / TPC));
+      for (int tt = 0; tt < TPC; ++tt) {
+        const bool ok = (int)mok & (int)((unsigned)(gy + tap_dy[tt]) < (unsigned)a.Hs) & (int)((unsigned)(gx + tap_dx[tt]) < (unsigned)a.Ws);
+        const unsigned off = ok ? (unsigned)((mrel + row + tap_rel[tt]) * (int)a.ldx * ES) : DG_OOB_OFF;
+        if constexpr (sizeof(T) == 2) gw[i][tt] = __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0);
+        else {
+          const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
+          gw[i][2 * tt] = v[0]; gw[i][2 * tt + 1] = v[1];
         }
       }
     }
   };
   const int tile0 = blockIdx.x * tiles_per_block;
-  if (tile0 * 128 < a.M) gather(tile0 * 128);
-  for (int t = 0; t < tiles_per_block; ++t) {
-    const int p0 = (tile0 + t) * 128;
-    if (p0 >= a.M) break;
+  auto publish = [&]() {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int e = tid + 256 * i, row = e / KCH, col = e % KCH;
+      const int row = row0 + (256 / KCH) * i;
       sX[row * KCH + (col ^ swz(row))] = make_uint4(gw[i][0], gw[i][1], gw[i][2], gw[i][3]);
     }
     __syncthreads();
-    if (t + 1 < tiles_per_block && p0 + 128 < a.M) gather(p0 + 128);
+  };
+  gather(tile0 * 128, tile0 * 128 < a.M);
+  publish();
+  // per tile: mask words | gather of tile t+1 | MFMAs | stores | barrier | gathered rows -> LDS | barrier.  The LDS write
+  // sits at the END of the body so that its wait is "all but the 12 stores issued after the gather" on every path
+  for (int t = 0; t < tiles_per_block; ++t) {
+    const int p0 = (tile0 + t) * 128;
+    if (p0 >= a.M) break;
+    // operand resources of this tile (destination pixel = GEMM row, everything based at the tile's first pixel) and its
+    // mask words, ahead of the next tile's gather: the epilogue then waits for these loads only
+    auto rsrc = [&](const void* p, long long ld, int es) {
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + (long long)p0 * ld * es), 0, (int)DG_OOB_OFF, 0x00020000);
+    };
+    EpiRes R;
+    R.rY = rsrc(a.y, a.ldy, ES);
+    R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
+    R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
+    R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
+    unsigned mbv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rel = wp * 64 + 16 * i + l15;
+      mbv[i] = epi64_bits<LEAN>(a, R, (cok && p0 + rel < a.M) ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF);
+    }
+    gather(p0 + 128, t + 1 < tiles_per_block);
     f32x4_t acc[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1450,9 +1538,17 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void gg_im2col_kernel(const GGAr
 #pragma unroll
         for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
     }
-    // (staging the tile through LDS for 16-byte row stores measured 15 % slower here too)
-    gg_epilogue<T, 128, 128, 64, 64, LEAN>(a, acc, p0, c0, wp, wc, l15, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rel = wp * 64 + 16 * i + l15;
+      const bool ok = cok && p0 + rel < a.M;
+      epi64_pixel<T, LEAN>(a, R, acc[0][i], acc[1][i], acc[2][i], acc[3][i], bias,
+                           ok ? (unsigned)((rel * R.ldy + cb16) * ES) : DG_OOB_OFF, ok ? (unsigned)((rel * R.ld1 + cb16) * ES) : DG_OOB_OFF,
+                           ok ? (unsigned)((rel * R.ld2 + cb16) * ES) : DG_OOB_OFF, ok ? (unsigned)((rel * R.ldm + cb16) * ES) : DG_OOB_OFF,
+                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i]);
+    }
     __syncthreads();
+    publish();
   }
 }
 
