@@ -390,12 +390,15 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
 // offsets 0 / 1 / 2 (34 input pixels for 32 output pixels), so 12.7 KB are staged per 1.6 MFLOP instead of 16 KB per
 // 1.0 MFLOP -- ablation builds of the per-tap kernel put half of its time in the global->register->LDS staging (the
 // VGPR->LDS store path, ~79 B/clk/CU), 15 % in the MFMAs.  BCO = 64 keeps the three accumulator sets at 96 registers.
+// The kernel is LDS-bandwidth-bound (transposing reads + staging writes), so the wave tile is chosen for fragment bytes per
+// MFMA: a wave owns ALL 64 adjoint channels x 32 input channels -- the two adjoint fragments are read once per 16 pixels
+// and shared by the three taps, each tap adds one input fragment: 5 KB per 6 MFMAs (a 32 x 64 wave tile reads 7 KB).
 template <typename T, int BCO>
 __global__ __launch_bounds__(256, 3) void wg3_kernel(const WGArgs a) {
   constexpr int EPC = DT<T>::EPC, BCI = 128, KP = 32, XR = KP + 2;
   constexpr int CPRU = BCO / EPC, CPRX = BCI / EPC;
   constexpr int NU = (KP * CPRU + 255) / 256, NX = (XR * CPRX + 255) / 256;
-  constexpr int FA = BCO / 64, FB = BCI / 64;
+  constexpr int FA = BCO / 32, FB = BCI / 128;      // wave = all BCO adjoint channels x 32 input channels (see above)
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
   constexpr int LDU = BCO + PADE, LDX = BCI + PADE;
   extern __shared__ __attribute__((aligned(16))) unsigned char wg_dsm[];   // 2 * (KP * LDU + XR * LDX) elements
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256, 3) void wg3_kernel(const WGArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][i][j][e] = 0.f;
 
-  const int wco = wave & 1, wci = wave >> 1;
+  const int wci = wave;
   const int r32 = lane & 31, h = lane >> 5;
   const int nsteps = (pend - pbeg + KP - 1) / KP;
   if (nsteps <= 0) return;
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(256, 3) void wg3_kernel(const WGArgs a) {
         const int k0 = kk * 16 + 8 * h + q;
 #pragma unroll
         for (int f = 0; f < FA; ++f) {
-          const int ch = wco * (BCO / 2) + 32 * f + 16 * grp16 + 4 * pp;
+          const int ch = 32 * f + 16 * grp16 + 4 * pp;
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + k0 * LDU + ch));
           s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(su + (k0 + 4) * LDU + ch));
           s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(256, 3) void wg3_kernel(const WGArgs a) {
           bf16x8_t fb[FB];
 #pragma unroll
           for (int f = 0; f < FB; ++f) {
-            const int ch = wci * (BCI / 2) + 32 * f + 16 * grp16 + 4 * pp;
+            const int ch = wci * (BCI / 4) + 32 * f + 16 * grp16 + 4 * pp;
             s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + (k0 + s) * LDX + ch));
             s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sx + (k0 + s + 4) * LDX + ch));
             s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -537,12 +540,12 @@ __global__ __launch_bounds__(256, 3) void wg3_kernel(const WGArgs a) {
       for (int k = 0; k < KP; k += 2) {
         float fa[FA];
 #pragma unroll
-        for (int f = 0; f < FA; ++f) fa[f] = su[(k + h) * LDU + wco * (BCO / 2) + 32 * f + r32];
+        for (int f = 0; f < FA; ++f) fa[f] = su[(k + h) * LDU + 32 * f + r32];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           float fb[FB];
 #pragma unroll
-          for (int f = 0; f < FB; ++f) fb[f] = sx[(k + h + s) * LDX + wci * (BCI / 2) + 32 * f + r32];
+          for (int f = 0; f < FB; ++f) fb[f] = sx[(k + h + s) * LDX + wci * (BCI / 4) + 32 * f + r32];
 #pragma unroll
           for (int i = 0; i < FA; ++i)
 #pragma unroll
@@ -564,10 +567,10 @@ __global__ __launch_bounds__(256, 3) void wg3_kernel(const WGArgs a) {
     for (int i = 0; i < FA; ++i)
 #pragma unroll
       for (int j = 0; j < FB; ++j) {
-        const int ci = ci0 + wci * (BCI / 2) + 32 * j + r32;
+        const int ci = ci0 + wci * (BCI / 4) + 32 * j + r32;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-          const int co = co0 + wco * (BCO / 2) + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          const int co = co0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
           if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (long long)co * ldw + tap * a.Cin + ci, acc[s][i][j][reg]);
         }
       }
@@ -599,6 +602,191 @@ static int wg3_launch(WGArgs& a, hipStream_t st) {
     attr = true;
   }
   hipLaunchKernelGGL((wg3_kernel<T, BCO>), dim3(ntiles, splits), dim3(256), lds, st, a);
+  return dg_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wide row-of-taps kernel (bf16): 128 adjoint channels x 128 input channels x the 3 taps of one row per workgroup.
+// The weight gradient re-reads its operands through L2 once per (co tile, ci tile, tap row) and removing the global
+// loads from wg3_kernel alone buys 30 %, so the lever is operand bytes per flop: this tile moves 5.4 KB per MFLOP against
+// 8.1 KB (64 x 128 x 3) and 16 KB (per-tap 128 x 128).  192 accumulator registers leave no room for staging registers:
+// the tiles go global -> LDS by DMA (buffer_load ... lds), three buffers, issued two 32-pixel steps ahead, ONE barrier per
+// step.  LDS rows are 256 B unpadded (the DMA writes lanes linearly); the 16-byte chunk index is XOR-swizzled with
+// (row & 3) << 2 on the SOURCE side, which keeps the four rows of a transposing read in four different 64-B bank groups.
+// Wave w owns all 128 adjoint channels x input channels [32w, 32w + 32): per 16 pixels 4 adjoint fragments shared by the
+// three taps + 1 input fragment per tap = 7 KB of LDS reads per 12 MFMAs.
+__global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
+  constexpr int BCO = 128, BCI = 128, KP = 32;
+  constexpr int ROWB = 256, SU_B = KP * ROWB, SX_B = 36 * ROWB, BUFB = SU_B + SX_B;   // x: 34 rows + 2 the last piece zero-fills
+  extern __shared__ __attribute__((aligned(16))) unsigned char wgw_dsm[];            // 3 * BUFB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned lin = gridDim.x <= 72 ? xcd_remap(lin0, gridDim.x * gridDim.y) : lin0;
+  const int bx = (int)(lin % gridDim.x), by = (int)(lin / gridDim.x);
+  const int ci_t = bx % a.nci_t;
+  const int trow = (bx / a.nci_t) % 3;
+  const int co_t = bx / (a.nci_t * 3);
+  const int co0 = co_t * BCO, ci0 = ci_t * BCI;
+  const int dr = trow - 1;
+  const int pbeg = by * a.ppb;
+  const int pend = min(a.Mpix, pbeg + a.ppb);
+  const int nsteps = (pend - pbeg + KP - 1) / KP;
+  if (nsteps <= 0) return;
+  const char* X = reinterpret_cast<const char*>(a.x);
+  const char* U = reinterpret_cast<const char*>(a.u);
+
+  // DMA lane constants: a piece = 4 rows x 256 B; lane -> (row 4p + lane / 16, physical chunk lane % 16)
+  const int drow = lane >> 4, lchunk = (lane & 15) ^ (drow << 2);
+  unsigned uoff[2], xoff[3];
+  int xr[3];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 4 * (wave + 4 * j) + drow, co = co0 + lchunk * 8;
+    if (co >= a.Cout) uoff[j] = WG_OOB_OFF;
+    else if (!a.u_ps) uoff[j] = (unsigned)(((long long)row * a.ldu + co) * 2);
+    else {
+      const int cchunk = co / 8, q = cchunk / a.cps_chunks, c = cchunk - q * a.cps_chunks;
+      uoff[j] = (unsigned)((((long long)(q >> 1) * (2 * a.Wo) + 2 * row + (q & 1)) * a.ldu + c * 8) * 2);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int row = 4 * (j < 2 ? wave + 4 * j : 8) + drow, ci = ci0 + lchunk * 8;
+    xr[j] = row;
+    xoff[j] = (row < KP + 2 && ci < a.Cin) ? (unsigned)(((long long)row * a.ldx + ci) * 2) : WG_OOB_OFF;
+  }
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)wgw_dsm));
+  typedef int i32x4w_t __attribute__((ext_vector_type(4)));
+  auto dma = [&](unsigned m0v, unsigned voff, const i32x4w_t& rs) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rs) : "memory");
+  };
+  auto make_rs = [&](const char* base) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4w_t rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
+    rs[2] = (int)WG_OOB_OFF;
+    rs[3] = 0x00020000;
+    return rs;
+  };
+  int s_wo = pbeg % a.Wo, s_ho, s_n;
+  { const int t = pbeg / a.Wo; s_ho = t % a.Ho; s_n = t / a.Ho; }
+  // tile t (32 output pixels of one row + the 34 input pixels under them) -> buffer buf
+  auto issue = [&](int buf, int t) {
+    const long long ub = !a.u_ps ? ((long long)(s_n * a.Ho + s_ho) * a.Wo + s_wo) * a.ldu
+                                 : ((long long)(s_n * 2 * a.Ho + 2 * s_ho) * (2 * a.Wo) + 2 * s_wo) * a.ldu;
+    const int hi = s_ho + dr;
+    const bool row_ok = (unsigned)hi < (unsigned)a.H;
+    const int wi0 = s_wo - 1;                                   // input column of tile row 0
+    const long long xb = ((long long)(s_n * a.H + (row_ok ? hi : 0)) * a.W + wi0) * a.ldx;
+    const i32x4w_t rsU = make_rs(U + ub * 2), rsX = make_rs(X + xb * 2);
+    const unsigned m0b = lds0 + (unsigned)buf * BUFB;
+    dma(m0b + (unsigned)wave * 1024u, uoff[0], rsU);
+    dma(m0b + (unsigned)(wave + 4) * 1024u, uoff[1], rsU);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned vo = (row_ok && (unsigned)(wi0 + xr[j]) < (unsigned)a.W) ? xoff[j] : WG_OOB_OFF;
+      dma(m0b + SU_B + (unsigned)(wave + 4 * j) * 1024u, vo, rsX);
+    }
+    if ((t & 3) == wave) {                                      // rows 32, 33 (+ two zero rows): one wave per step, in turn
+      const unsigned vo = (row_ok && (unsigned)(wi0 + xr[2]) < (unsigned)a.W) ? xoff[2] : WG_OOB_OFF;
+      dma(m0b + SU_B + 8u * 1024u, vo, rsX);
+    }
+    s_wo += KP;
+    if (s_wo >= a.Wo) { s_wo = 0; if (++s_ho == a.Ho) { s_ho = 0; ++s_n; } }
+  };
+
+  f32x16_t acc[3][4];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[s][f][e] = 0.f;
+
+  // fragment read offsets (bytes inside a buffer): row 8h + q (+ tap), 64-B group XOR (row & 3), 32 * grp16 + 8 * pp inside
+  const int h = lane >> 5, grp16 = (lane >> 4) & 1, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, r32 = lane & 31;
+  const int bu = (8 * h + q) * ROWB + (q << 6) + 32 * grp16 + 8 * pp;          // adjoint fragment f at bu ^ (f << 6)
+  int bxs[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) bxs[s] = SU_B + (8 * h + q + s) * ROWB + ((wave ^ ((q + s) & 3)) << 6) + 32 * grp16 + 8 * pp;
+
+  issue(0, 0);
+  if (nsteps > 1) issue(1, 1);
+  // a wave has 4 or 5 pieces per tile in flight: "at most 4 outstanding" = everything older than the newest tile landed
+  if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  for (int ks = 0; ks < nsteps; ++ks) {
+    const bool ahead = ks + 2 < nsteps;
+    int nb = cur + 2; if (nb >= 3) nb -= 3;
+    if (ahead) issue(nb, ks + 2);            // buffer (ks + 2) % 3 was last read in step ks - 1, behind that step's barrier
+    const unsigned char* sb = wgw_dsm + cur * BUFB;
+#pragma unroll
+    for (int kk = 0; kk < KP / 16; ++kk) {
+      bf16x8_t fa[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const unsigned char* pa = sb + (bu ^ (f << 6)) + kk * 16 * ROWB;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa + 4 * ROWB));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fa[f] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const unsigned char* pb = sb + bxs[s] + kk * 16 * ROWB;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + 4 * ROWB));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, v);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[s][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f], fb, acc[s][f], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);       // 192 accumulator registers: keep one input fragment live at a time
+      }
+    }
+    if (ahead) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (++cur == 3) cur = 0;
+  }
+
+  // epilogue: one lane-constant 32-bit offset, everything else of an element's address is workgroup-uniform (scalar base)
+  const long long ldw = 9ll * a.Cin;
+  const int ci = ci0 + wave * 32 + r32;
+  const unsigned lane_off = (unsigned)((((long long)co0 + 4 * h) * ldw + ci) * 4);
+  const bool ci_ok = ci < a.Cin;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int tap = trow * 3 + s;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int cor = 32 * f + (reg & 3) + 8 * (reg >> 2);             // + co0 + 4h
+        char* const base = reinterpret_cast<char*>(a.dw) + ((long long)cor * ldw + (long long)tap * a.Cin) * 4;
+        if (ci_ok && co0 + cor + 4 * h < a.Cout) atomicAdd(reinterpret_cast<float*>(base + lane_off), acc[s][f][reg]);
+      }
+  }
+}
+
+static int wg3w_launch(WGArgs& a, hipStream_t st) {
+  constexpr int BCO = 128, BCI = 128;
+  const int nco_t = (a.Cout + BCO - 1) / BCO;
+  a.nci_t = (a.Cin + BCI - 1) / BCI;
+  const int ntiles = nco_t * 3 * a.nci_t;
+  const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
+  long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
+  if (cap < 512) cap = 512;
+  const int tb = 2048 < cap ? 2048 : (int)cap;                                 // 512 workgroup slots (2 per CU)
+  int splits = (tb + ntiles - 1) / ntiles;
+  const int max_splits = (a.Mpix + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.ppb = ((a.Mpix + splits - 1) / splits + 63) / 64 * 64;
+  splits = (a.Mpix + a.ppb - 1) / a.ppb;
+  constexpr int lds = 3 * (32 * 256 + 36 * 256);
+  hipLaunchKernelGGL(wg3w_kernel, dim3(ntiles, splits), dim3(256), lds, st, a);
   return dg_check_launch();
 }
 
@@ -635,7 +823,10 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
   // measured per layer against the per-tap kernel: +4-10 % with >= 2 input-channel tiles or multi-megapixel batches,
   // -20 % on the 128-channel 128^2 layers (too few workgroups per pixel range)
   static const bool no_rows = getenv("DG_WG_NOROWS") != nullptr;
-  if (!no_rows && g->stride == 1 && a.Wo % 32 == 0 && a.Cout >= 64 && (a.Cin >= 256 || (a.Cin >= 64 && a.Mpix >= (1 << 22))))
+  if (!no_rows && g->stride == 1 && a.Wo % 32 == 0 && a.Cout >= 64 && (a.Cin >= 256 || (a.Cin >= 64 && a.Mpix >= (1 << 22)))) {
+    static const bool no_wide = getenv("DG_WG_NOWIDE") != nullptr;
+    if (!no_wide && g->dtype == DG_BF16 && a.Cout >= 128 && a.Cin >= 128) return wg3w_launch(a, st);
     return g->dtype == DG_F32 ? wg3_launch<float>(a, st) : wg3_launch<bf16_t>(a, st);
+  }
   return g->dtype == DG_F32 ? wg_launch<float>(a, st) : wg_launch<bf16_t>(a, st);
 }
