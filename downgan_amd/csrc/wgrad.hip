@@ -615,9 +615,13 @@ static int wg3_launch(WGArgs& a, hipStream_t st) {
 // (row & 3) << 2 on the SOURCE side, which keeps the four rows of a transposing read in four different 64-B bank groups.
 // Wave w owns all 128 adjoint channels x input channels [32w, 32w + 32): per 16 pixels 4 adjoint fragments shared by the
 // three taps + 1 input fragment per tap = 7 KB of LDS reads per 12 MFMAs.
+template <bool S2>
 __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   constexpr int BCO = 128, BCI = 128, KP = 32;
-  constexpr int ROWB = 256, SU_B = KP * ROWB, SX_B = 36 * ROWB, BUFB = SU_B + SX_B;   // x: 34 rows + 2 the last piece zero-fills
+  // x tile: 34 rows (stride 1) / 65 rows (S2: input columns 2wo - 1 .. 2wo + 63, tap s of output pixel k = row 2k + s),
+  // rounded up to whole 4-row DMA pieces (the surplus rows are zero-filled and never read)
+  constexpr int XROWS = S2 ? 65 : KP + 2, NXP = S2 ? 4 : 2, LASTP = 4 * NXP, XALLOC = 4 * (LASTP + 1);
+  constexpr int ROWB = 256, SU_B = KP * ROWB, SX_B = XALLOC * ROWB, BUFB = SU_B + SX_B;
   extern __shared__ __attribute__((aligned(16))) unsigned char wgw_dsm[];            // 3 * BUFB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
@@ -637,8 +641,11 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
 
   // DMA lane constants: a piece = 4 rows x 256 B; lane -> (row 4p + lane / 16, physical chunk lane % 16)
   const int drow = lane >> 4, lchunk = (lane & 15) ^ (drow << 2);
-  unsigned uoff[2], xoff[3];
-  int xr[3];
+  // S2: the rows of a transposing read are 2 apart, so the swizzle key is (row >> 1) & 3 (piece p = wave + 4j: p & 1 = wave & 1)
+  const int lcx = S2 ? (lane & 15) ^ (((((wave & 1) << 1) + (drow >> 1)) & 3) << 2) : lchunk;
+  const int lcx_last = S2 ? (lane & 15) ^ ((drow >> 1) << 2) : lchunk;
+  unsigned uoff[2], xoff[NXP + 1];
+  int xr[NXP + 1];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int row = 4 * (wave + 4 * j) + drow, co = co0 + lchunk * 8;
@@ -650,10 +657,10 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int row = 4 * (j < 2 ? wave + 4 * j : 8) + drow, ci = ci0 + lchunk * 8;
+  for (int j = 0; j <= NXP; ++j) {
+    const int row = 4 * (j < NXP ? wave + 4 * j : LASTP) + drow, ci = ci0 + (j < NXP ? lcx : lcx_last) * 8;
     xr[j] = row;
-    xoff[j] = (row < KP + 2 && ci < a.Cin) ? (unsigned)(((long long)row * a.ldx + ci) * 2) : WG_OOB_OFF;
+    xoff[j] = (row < XROWS && ci < a.Cin) ? (unsigned)(((long long)row * a.ldx + ci) * 2) : WG_OOB_OFF;
   }
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)wgw_dsm));
   typedef int i32x4w_t __attribute__((ext_vector_type(4)));
@@ -675,22 +682,22 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   auto issue = [&](int buf, int t) {
     const long long ub = !a.u_ps ? ((long long)(s_n * a.Ho + s_ho) * a.Wo + s_wo) * a.ldu
                                  : ((long long)(s_n * 2 * a.Ho + 2 * s_ho) * (2 * a.Wo) + 2 * s_wo) * a.ldu;
-    const int hi = s_ho + dr;
+    const int hi = (S2 ? 2 * s_ho : s_ho) + dr;
     const bool row_ok = (unsigned)hi < (unsigned)a.H;
-    const int wi0 = s_wo - 1;                                   // input column of tile row 0
+    const int wi0 = (S2 ? 2 * s_wo : s_wo) - 1;                 // input column of tile row 0
     const long long xb = ((long long)(s_n * a.H + (row_ok ? hi : 0)) * a.W + wi0) * a.ldx;
     const i32x4w_t rsU = make_rs(U + ub * 2), rsX = make_rs(X + xb * 2);
     const unsigned m0b = lds0 + (unsigned)buf * BUFB;
     dma(m0b + (unsigned)wave * 1024u, uoff[0], rsU);
     dma(m0b + (unsigned)(wave + 4) * 1024u, uoff[1], rsU);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NXP; ++j) {
       const unsigned vo = (row_ok && (unsigned)(wi0 + xr[j]) < (unsigned)a.W) ? xoff[j] : WG_OOB_OFF;
       dma(m0b + SU_B + (unsigned)(wave + 4 * j) * 1024u, vo, rsX);
     }
-    if ((t & 3) == wave) {                                      // rows 32, 33 (+ two zero rows): one wave per step, in turn
-      const unsigned vo = (row_ok && (unsigned)(wi0 + xr[2]) < (unsigned)a.W) ? xoff[2] : WG_OOB_OFF;
-      dma(m0b + SU_B + 8u * 1024u, vo, rsX);
+    if ((t & 3) == wave) {                                      // the last rows (+ zero rows): one wave per step, in turn
+      const unsigned vo = (row_ok && (unsigned)(wi0 + xr[NXP]) < (unsigned)a.W) ? xoff[NXP] : WG_OOB_OFF;
+      dma(m0b + SU_B + (unsigned)LASTP * 1024u, vo, rsX);
     }
     s_wo += KP;
     if (s_wo >= a.Wo) { s_wo = 0; if (++s_ho == a.Ho) { s_ho = 0; ++s_n; } }
@@ -709,12 +716,22 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   const int bu = (8 * h + q) * ROWB + (q << 6) + 32 * grp16 + 8 * pp;          // adjoint fragment f at bu ^ (f << 6)
   int bxs[3];
 #pragma unroll
-  for (int s = 0; s < 3; ++s) bxs[s] = SU_B + (8 * h + q + s) * ROWB + ((wave ^ ((q + s) & 3)) << 6) + 32 * grp16 + 8 * pp;
+  for (int s = 0; s < 3; ++s) {
+    const int row = S2 ? 2 * (8 * h + q) + s : 8 * h + q + s;
+    bxs[s] = SU_B + row * ROWB + ((wave ^ ((S2 ? row >> 1 : row) & 3)) << 6) + 32 * grp16 + 8 * pp;
+  }
+  constexpr int XK = S2 ? 2 : 1;                                 // tile rows per output pixel
 
   issue(0, 0);
   if (nsteps > 1) issue(1, 1);
-  // a wave has 4 or 5 pieces per tile in flight: "at most 4 outstanding" = everything older than the newest tile landed
-  if (nsteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // a wave has NXP + 2 or NXP + 3 pieces per tile in flight: "at most NXP + 2 outstanding" = everything older than the
+  // newest tile has landed
+  auto wait_older = [&](bool newest_in_flight) {
+    if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (S2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  };
+  wait_older(nsteps > 1);
   __syncthreads();
   int cur = 0;
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -736,9 +753,9 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
       }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        const unsigned char* pb = sb + bxs[s] + kk * 16 * ROWB;
+        const unsigned char* pb = sb + bxs[s] + kk * 16 * XK * ROWB;
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + 4 * ROWB));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + 4 * XK * ROWB));
         const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, v);
 #pragma unroll
@@ -746,7 +763,7 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
         __builtin_amdgcn_sched_barrier(0);       // 192 accumulator registers: keep one input fragment live at a time
       }
     }
-    if (ahead) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_older(ahead);
     __syncthreads();
     if (++cur == 3) cur = 0;
   }
@@ -770,6 +787,7 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   }
 }
 
+template <bool S2>
 static int wg3w_launch(WGArgs& a, hipStream_t st) {
   constexpr int BCO = 128, BCI = 128;
   const int nco_t = (a.Cout + BCO - 1) / BCO;
@@ -785,8 +803,14 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
   if (splits < 1) splits = 1;
   a.ppb = ((a.Mpix + splits - 1) / splits + 63) / 64 * 64;
   splits = (a.Mpix + a.ppb - 1) / a.ppb;
-  constexpr int lds = 3 * (32 * 256 + 36 * 256);
-  hipLaunchKernelGGL(wg3w_kernel, dim3(ntiles, splits), dim3(256), lds, st, a);
+  constexpr int lds = 3 * (32 * 256 + (S2 ? 68 : 36) * 256);
+  static bool attr = false;
+  if (!attr && lds > 65536) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wg3w_kernel<S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return DG_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((wg3w_kernel<S2>), dim3(ntiles, splits), dim3(256), lds, st, a);
   return dg_check_launch();
 }
 
@@ -825,8 +849,13 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
   static const bool no_rows = getenv("DG_WG_NOROWS") != nullptr;
   if (!no_rows && g->stride == 1 && a.Wo % 32 == 0 && a.Cout >= 64 && (a.Cin >= 256 || (a.Cin >= 64 && a.Mpix >= (1 << 22)))) {
     static const bool no_wide = getenv("DG_WG_NOWIDE") != nullptr;
-    if (!no_wide && g->dtype == DG_BF16 && a.Cout >= 128 && a.Cin >= 128) return wg3w_launch(a, st);
+    if (!no_wide && g->dtype == DG_BF16 && a.Cout >= 128 && a.Cin >= 128) return wg3w_launch<false>(a, st);
     return g->dtype == DG_F32 ? wg3_launch<float>(a, st) : wg3_launch<bf16_t>(a, st);
   }
+  // stride 2 on the wide kernel (x tile of 65 input pixels per 32 output pixels)
+  static const bool no_wide_s2 = getenv("DG_WG_NOWIDE") != nullptr || getenv("DG_WG_NOWIDES2") != nullptr;
+  if (!no_rows && !no_wide_s2 && g->stride == 2 && g->dtype == DG_BF16 && a.Wo % 32 == 0 && a.Cout >= 128 && a.Cin >= 128 &&
+      !g->pixel_shuffle && (a.Cin >= 256 || a.Mpix >= (1 << 20)))
+    return wg3w_launch<true>(a, st);
   return g->dtype == DG_F32 ? wg_launch<float>(a, st) : wg_launch<bf16_t>(a, st);
 }

@@ -58,6 +58,9 @@ CONVS = [
     (1, 32, 32, 256, 256, 1, True),     # ... with a pixel-shuffled adjoint
     (2, 64, 48, 128, 128, 2, False),    # stride 2 with a single reduction-channel block (the critic's features.2 shape class)
     (1, 32, 48, 192, 64, 2, False),     # ... and a partial channel tile
+    (1, 64, 64, 256, 128, 2, False),    # stride 2, Wo % 32 == 0, >= 256 input channels: wide DMA-staged weight-gradient kernel
+    (2, 64, 128, 320, 192, 2, False),   # ... ragged channel tiles, two images, Wo = 64
+    (1, 32, 64, 384, 256, 1, False),    # stride-1 wide weight-gradient kernel: 3 input-channel tiles, 2 adjoint tiles
 ]
 
 
