@@ -722,6 +722,11 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   }
   constexpr int XK = S2 ? 2 : 1;                                 // tile rows per output pixel
 
+  // bias gradient (column sums of the adjoint) on the side: the workgroups of the centre tap row and first input-channel
+  // tile already hold every adjoint fragment in registers; wave 0 adds them up (a lane's 8 values belong to one channel)
+  const bool do_db = a.db != nullptr && trow == 1 && ci_t == 0 && wave == 0;
+  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+
   issue(0, 0);
   if (nsteps > 1) issue(1, 1);
   // a wave has NXP + 2 or NXP + 3 pieces per tile in flight: "at most NXP + 2 outstanding" = everything older than the
@@ -751,6 +756,14 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
         const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         fa[f] = __builtin_bit_cast(bf16x8_t, v);
       }
+      if (do_db) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const u32x4w_t w4 = __builtin_bit_cast(u32x4w_t, fa[f]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dbacc[f] += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);
+        }
+      }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const unsigned char* pb = sb + bxs[s] + kk * 16 * XK * ROWB;
@@ -768,6 +781,11 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
     if (++cur == 3) cur = 0;
   }
 
+  if (do_db) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+      if (co0 + 32 * f + r32 < a.Cout) atomicAdd(a.db + co0 + 32 * f + r32, dbacc[f]);
+  }
   // epilogue: one lane-constant 32-bit offset, everything else of an element's address is workgroup-uniform (scalar base)
   const long long ldw = 9ll * a.Cin;
   const int ci = ci0 + wave * 32 + r32;
@@ -839,23 +857,27 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
   static const bool no_im2col = getenv("DG_WG_NOIM2COL") != nullptr;
   if (!no_im2col && g->cin_real > 0 && g->cin_real <= 2 && g->stride == 1 && !g->pixel_shuffle && a.Wo % 32 == 0)
     return g->dtype == DG_F32 ? wg_launch_im2col<float>(a, st) : wg_launch_im2col<bf16_t>(a, st);
-  if (db) {   // bias gradient as a separate column-sum pass over the adjoint
+  // measured per layer against the per-tap kernel: +4-10 % with >= 2 input-channel tiles or multi-megapixel batches,
+  // -20 % on the 128-channel 128^2 layers (too few workgroups per pixel range)
+  static const bool no_rows = getenv("DG_WG_NOROWS") != nullptr;
+  static const bool no_wide = getenv("DG_WG_NOWIDE") != nullptr;
+  static const bool no_wide_s2 = no_wide || getenv("DG_WG_NOWIDES2") != nullptr;
+  const bool rows = !no_rows && g->stride == 1 && a.Wo % 32 == 0 && a.Cout >= 64 && (a.Cin >= 256 || (a.Cin >= 64 && a.Mpix >= (1 << 22)));
+  const bool wide = g->dtype == DG_BF16 && a.Cout >= 128 && a.Cin >= 128;
+  const bool wide_s1 = rows && wide && !no_wide;
+  // stride 2 on the wide kernel (x tile of 65 input pixels per 32 output pixels)
+  const bool wide_s2 = !no_rows && !no_wide_s2 && wide && g->stride == 2 && a.Wo % 32 == 0 && !g->pixel_shuffle &&
+                       (a.Cin >= 256 || a.Mpix >= (1 << 20));
+  static const bool no_fused_db = getenv("DG_WG_NOFUSEDDB") != nullptr;
+  const bool fused_db = db && (wide_s1 || wide_s2) && !g->pixel_shuffle && !no_fused_db;   // the wide kernel sums the adjoint itself
+  if (db && !fused_db) {   // bias gradient as a separate column-sum pass over the adjoint
     if (g->pixel_shuffle) return DG_ERR_BAD_ARG;
     int rc = dg_colsum(g->dtype, dy, mp, g->ldy, 1, g->ldy, g->Cout, db, stream);
     if (rc) return rc;
   }
-  // measured per layer against the per-tap kernel: +4-10 % with >= 2 input-channel tiles or multi-megapixel batches,
-  // -20 % on the 128-channel 128^2 layers (too few workgroups per pixel range)
-  static const bool no_rows = getenv("DG_WG_NOROWS") != nullptr;
-  if (!no_rows && g->stride == 1 && a.Wo % 32 == 0 && a.Cout >= 64 && (a.Cin >= 256 || (a.Cin >= 64 && a.Mpix >= (1 << 22)))) {
-    static const bool no_wide = getenv("DG_WG_NOWIDE") != nullptr;
-    if (!no_wide && g->dtype == DG_BF16 && a.Cout >= 128 && a.Cin >= 128) return wg3w_launch<false>(a, st);
-    return g->dtype == DG_F32 ? wg3_launch<float>(a, st) : wg3_launch<bf16_t>(a, st);
-  }
-  // stride 2 on the wide kernel (x tile of 65 input pixels per 32 output pixels)
-  static const bool no_wide_s2 = getenv("DG_WG_NOWIDE") != nullptr || getenv("DG_WG_NOWIDES2") != nullptr;
-  if (!no_rows && !no_wide_s2 && g->stride == 2 && g->dtype == DG_BF16 && a.Wo % 32 == 0 && a.Cout >= 128 && a.Cin >= 128 &&
-      !g->pixel_shuffle && (a.Cin >= 256 || a.Mpix >= (1 << 20)))
-    return wg3w_launch<true>(a, st);
+  a.db = fused_db ? db : nullptr;
+  if (wide_s1) return wg3w_launch<false>(a, st);
+  if (rows) return g->dtype == DG_F32 ? wg3_launch<float>(a, st) : wg3_launch<bf16_t>(a, st);
+  if (wide_s2) return wg3w_launch<true>(a, st);
   return g->dtype == DG_F32 ? wg_launch<float>(a, st) : wg_launch<bf16_t>(a, st);
 }

@@ -116,12 +116,17 @@ def test_conv_wgrad(dtype, cfg):
     dy = rnd(emu.out_shape(cv), emu.tdtype, g)
     dw_ref = torch.randn(co * 9 * ci, generator=g)
     dw = dw_ref.clone().cuda()
-    emu.conv_wgrad(cv, x, dy, dw_ref)
-    hip.conv_wgrad(cv, x.cuda(), dy.cuda(), dw)
+    # bias gradient (accumulated into db like dw): a separate column-sum pass, or fused into the wide weight-gradient kernel
+    db_ref = None if ps else torch.randn(co, generator=g)
+    db = None if ps else db_ref.clone().cuda()
+    emu.conv_wgrad(cv, x, dy, dw_ref, db=db_ref)
+    hip.conv_wgrad(cv, x.cuda(), dy.cuda(), dw, db=db)
     a, b = dw.cpu(), dw_ref
     scale = float(b.abs().max())
     tol = 1e-5 if dtype == "f32" else 1e-4   # inputs are identical bf16 values; accumulation is fp32 in both
     assert (a - b).abs().max().item() <= tol * scale * 8, (cfg, (a - b).abs().max().item(), scale)
+    if not ps:
+        assert (db.cpu() - db_ref).abs().max().item() <= tol * 8 * float(db_ref.abs().max()), cfg
 
 
 def test_conv_slab_views_f32():
