@@ -465,10 +465,10 @@ class NativeGenerator:
         GW = lambda n: P.grad(n + ".weight").reshape(-1)
         GB = lambda n: P.grad(n + ".bias")
         # conv3.2 / conv3.0
-        o.conv_wgrad(self.cv_c32, self.c30, dfake, GW("conv3.2")); o.colsum(dfake, GB("conv3.2"))
+        o.conv_wgrad(self.cv_c32, self.c30, dfake, GW("conv3.2"), db=GB("conv3.2"))
         o.conv_dgrad(self.cv_c32, dfake, WD("conv3.2"), bw["d_c30"], mask=self.c30, mask_slope=G_SLOPE)
         top = self.ups[-1] if self.nup else self.trunk
-        o.conv_wgrad(self.cv_c30, top, bw["d_c30"], GW("conv3.0")); o.colsum(bw["d_c30"], GB("conv3.0"))
+        o.conv_wgrad(self.cv_c30, top, bw["d_c30"], GW("conv3.0"), db=GB("conv3.0"))
         dcur = bw["d_ups"][-1] if self.nup else bw["d_trunk"]
         if self.nup:
             o.conv_dgrad(self.cv_c30, bw["d_c30"], WD("conv3.0"), dcur, mask=self.ups[-1], mask_slope=G_SLOPE)
@@ -487,7 +487,7 @@ class NativeGenerator:
                 dcur = bw["d_trunk"]
         d_trunk = dcur                                   # = d out1 (skip) = d out2
         # conv2
-        o.conv_wgrad(self.cv_conv2, self._saved[self.ndrb][..., :F_], d_trunk, GW("conv2")); o.colsum(d_trunk, GB("conv2"))
+        o.conv_wgrad(self.cv_conv2, self._saved[self.ndrb][..., :F_], d_trunk, GW("conv2"), db=GB("conv2"))
         gy = bw["gy"][0]
         o.conv_dgrad(self.cv_conv2, d_trunk, WD("conv2"), gy)
         gyi = 0
@@ -500,13 +500,13 @@ class NativeGenerator:
                 slab, gs = self._saved[d], bw["gslab"][d & 1]
                 pre = f"res_blocks.{i}.dense_blocks.{j}.b"
                 o.axpby(bw["d5"], go, RES_SCALE)          # d b5-out = 0.2 * d o
-                o.conv_wgrad(self.cv_b[4], slab, bw["d5"], GW(f"{pre}5.0")); o.colsum(bw["d5"], GB(f"{pre}5.0"))
+                o.conv_wgrad(self.cv_b[4], slab, bw["d5"], GW(f"{pre}5.0"), db=GB(f"{pre}5.0"))
                 o.conv_dgrad(self.cv_b[4], bw["d5"], WD(f"{pre}5.0"), gs)
                 o.axpby(gs[..., :F_], gs[..., :F_], 1.0, go, 1.0)        # + identity path of o = 0.2*b5 + x
                 for k in range(4, 0, -1):
                     uk = gs[..., k * F_:(k + 1) * F_]
                     o.mask_mul(uk, slab[..., k * F_:(k + 1) * F_], G_SLOPE)
-                    o.conv_wgrad(self.cv_b[k - 1], slab[..., :k * F_], uk, GW(f"{pre}{k}.0")); o.colsum(uk, GB(f"{pre}{k}.0"))
+                    o.conv_wgrad(self.cv_b[k - 1], slab[..., :k * F_], uk, GW(f"{pre}{k}.0"), db=GB(f"{pre}{k}.0"))
                     o.conv_dgrad(self.cv_b[k - 1], uk, WD(f"{pre}{k}.0"), gs[..., :k * F_], accumulate=True)
                 go = gs[..., :F_]                         # d x_drb = d o of the previous dense block
             gyn = bw["gy"][gyi ^ 1]
