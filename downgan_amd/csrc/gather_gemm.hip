@@ -1163,6 +1163,10 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     return fb_lane + ((wave * 4 + 1 + dy) * PW + 1 + dx) * PITCH;
   };
 
+#ifdef DG_STAMP
+  unsigned long long tK0 = 0, tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, sAB = 0, sBC = 0, sCD = 0, sDE = 0, tL0 = 0;
+  STAMP(tK0);
+#endif
   load_patch(0);
   int cb = 0, tap = 0, cbw = 0, tapw = 0;
   dma_w(0, 0, 0);
@@ -1177,7 +1181,9 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   const char* pb = patch_ptr(0, 0);
   int pa = 0;
   read_frags(fa, fb, pa, pb, 0);
+  STAMP(tL0);
   for (int s = 0; s < nsteps; ++s) {
+    STAMP(tA);
     const bool more = s + 1 < nsteps;
     int ntap = tap + 1, ncbn = cb;
     const int ntaps_cb = ntaps_of(cb);
@@ -1194,10 +1200,13 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     __builtin_amdgcn_sched_barrier(0);
     if (patch_now) load_patch(cb + 1);
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(tB);
 #pragma unroll
     for (int q = 0; q < 4; ++q) mma_rows(fa, fb, 2 * q);
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(tC);
     if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
+    STAMP(tD);
     pa = ((s + 1) & 1) * (BC * WROW);
     pb = patch_ptr(ncbn < ncb ? ncbn : 0, ntap);
     if (swap) {                      // channel-block boundary: the single-buffered patch is rewritten, then published
@@ -1215,8 +1224,23 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     adv(cbw, tapw);
     __builtin_amdgcn_sched_barrier(0);
     tap = ntap; cb = ncbn;
+    STAMP(tE);
+#ifdef DG_STAMP
+    sAB += tB - tA; sBC += tC - tB; sCD += tD - tC; sDE += tE - tD;
+#endif
   }
+#ifdef DG_STAMP
+  unsigned long long tL1, tX;
+  STAMP(tL1);
+#endif
   halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0, wave, 0, l15, g);
+#ifdef DG_STAMP
+  STAMP(tX);
+  if (blockIdx.x < 2 && lane == 0) {
+    unsigned long long* o = g_stamps + (blockIdx.x * 8 + wave) * 8;
+    o[0] = sAB; o[1] = sBC; o[2] = sCD; o[3] = sDE; o[4] = (unsigned long long)nsteps; o[5] = tL1 - tL0; o[6] = tX - tL1; o[7] = tL0 - tK0;
+  }
+#endif
 }
 
 template <typename T, bool S2>

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-segment cycle sums of the halo kernel's tap-step.
+"""Diagnostic: per-segment cycle sums of the four-wave halo kernel's tap-step (gg_halo4w_kernel, DG_STAMP build).
 
     make -C downgan_amd/csrc stamp && DG_LIB_OVERRIDE=downgan_amd/csrc/libdowngan_hip_stamp.so python tools/stamp_probe.py
 """
@@ -35,8 +35,8 @@ for name, N, H, ci, co, st, op in CASES:
     assert o.lib.dg_debug_stamps(buf) == 0
     print(name)
     for b in range(2):
-        for wv in range(8):
+        for wv in range(4):
             v = [buf[(b * 8 + wv) * 8 + k] for k in range(8)]
             n = max(v[4], 1)
-            print(f"  blk {b} wave {wv}: steps {v[4]:3d}  per-step cycles: first half (mma0,1 issued + reads 2,3 issued) {v[0]/n:7.0f}  barrier {v[1]/n:7.0f}  second half {v[2]/n:6.0f}"
-                  f"  sum {sum(v[:4])/n:7.0f} | loop {v[5]:8d}  epilogue {v[6]:7d}")
+            print(f"  blk {b} wave {wv}: steps {v[4]:3d}  per-step cycles: mma(k0)+reads k1 {v[0]/n:6.0f}  mma(k1) {v[1]/n:6.0f}  barrier {v[2]/n:6.0f}  reads k0'+DMA {v[3]/n:6.0f}"
+                  f"  sum {sum(v[:4])/n:6.0f} | prologue {v[7]:7d}  loop {v[5]:8d}  epilogue {v[6]:7d}")
