@@ -23,6 +23,7 @@
 #include "dg_internal.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 // bit mask of the kernel variants the last dg_conv3x3_fwd / _dgrad call of this thread launched (bench.py tags its
 // live timings with it): 1 generic, 2 fast, 8 halo, 16 im2col
@@ -137,7 +138,10 @@ __device__ __forceinline__ unsigned epi64_bits(const GGArgs& a, const EpiRes& R,
   if (LEAN || a.mask_bits) return __builtin_amdgcn_raw_buffer_load_b16(R.rbi, (LEAN && !a.mask_bits) ? DG_OOB_OFF : boff, 0, 0);
   return 0u;
 }
-template <typename T, bool LEAN>
+// F >= 0: the activation / mask_bits / out_bits flags as compile-time bits 1 / 2 / 4 (straight-line code, picked once per
+// epilogue by halo_epilogue: with run-time flags every pixel row carries ~20 uniform branches and the register moves of
+// their merge points, and the epilogue of a 9..18-step tile was bound by instruction issue, not by its stores); F < 0: run-time.
+template <typename T, bool LEAN, int F = -1>
 __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, const f32x4_t& f0, const f32x4_t& f1, const f32x4_t& f2,
                                             const f32x4_t& f3, const float (&bias)[16], unsigned offy, unsigned off1, unsigned off2,
                                             unsigned offm, unsigned boff, unsigned mb) {
@@ -145,20 +149,27 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
   constexpr int NU = IO::NU, CPU = IO::CPU;
   u32x4_t v1[NU], v2[NU], vm[NU], va[NU];
   unsigned ob = 0;
+  const bool f_act = F < 0 ? a.has_act != 0 : (F & 1) != 0;
+  const bool f_mb = F < 0 ? a.mask_bits != nullptr : (F & 2) != 0;
+  const bool f_ob = F < 0 ? a.out_bits != nullptr : (F & 4) != 0;
+  const bool f_r1 = F < 0 ? !LEAN && a.r1 != nullptr : (F & 8) != 0;
+  const bool f_r2 = F < 0 ? !LEAN && a.r2 != nullptr : (F & 16) != 0;
+  const bool f_mk = F < 0 ? !LEAN && a.mask != nullptr : (F & 32) != 0;
+  const bool f_ac = F < 0 ? !LEAN && a.accumulate != 0 : (F & 64) != 0;
   // LEAN runs inside a tile loop whose memory operations must be unconditional (see gg_im2col_kernel): absent bit-mask
   // operands become out-of-range offsets (the load returns 0, the store is dropped)
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    if (!LEAN && a.r1) v1[u] = __builtin_amdgcn_raw_buffer_load_b128(R.r1, off1, u * 16, 0);
-    if (!LEAN && a.r2) v2[u] = __builtin_amdgcn_raw_buffer_load_b128(R.r2, off2, u * 16, 0);
-    if (!LEAN && a.mask) vm[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rm, offm, u * 16, 0);
-    if (!LEAN && a.accumulate) va[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rY, offy, u * 16, 0);
+    if (f_r1) v1[u] = __builtin_amdgcn_raw_buffer_load_b128(R.r1, off1, u * 16, 0);
+    if (f_r2) v2[u] = __builtin_amdgcn_raw_buffer_load_b128(R.r2, off2, u * 16, 0);
+    if (f_mk) vm[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rm, offm, u * 16, 0);
+    if (f_ac) va[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rY, offy, u * 16, 0);
   }
   float v[16];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { v[e] = f0[e] + bias[e]; v[4 + e] = f1[e] + bias[4 + e]; v[8 + e] = f2[e] + bias[8 + e]; v[12 + e] = f3[e] + bias[12 + e]; }
   // (pure-ALU parts may sit behind uniform branches: only the memory operations have to be unconditional)
-  if (a.has_act) {
+  if (f_act) {
     if (a.act_slope >= 0.f && a.act_slope <= 1.f) {          // max(v, v * slope) == leaky(v) for slopes in [0, 1]: 2 operations, not 3
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = __builtin_fmaxf(v[k], v[k] * a.act_slope);
@@ -171,37 +182,38 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
   for (int u = 0; u < NU; ++u) {
     float r[CPU];
     float* vu = v + u * CPU;
-    if (!LEAN && a.r1) {
+    if (f_r1) {
       IO::unpack(v1[u], r);
 #pragma unroll
       for (int e = 0; e < CPU; ++e) vu[e] = vu[e] * a.s1 + r[e];
     }
-    if (!LEAN && a.r2) {
+    if (f_r2) {
       IO::unpack(v2[u], r);
 #pragma unroll
       for (int e = 0; e < CPU; ++e) vu[e] = vu[e] * a.s2 + r[e];
     }
-    if (!LEAN && a.mask) {
+    if (f_mk) {
       IO::unpack(vm[u], r);
 #pragma unroll
       for (int e = 0; e < CPU; ++e) vu[e] *= leaky_grad(r[e], a.mask_slope);
     }
-    if (a.mask_bits) {
+    if (f_mb) {
 #pragma unroll
       for (int e = 0; e < CPU; ++e) vu[e] *= ((mb >> (u * CPU + e)) & 1u) ? 1.f : a.mask_slope;
     }
-    if (!LEAN && a.accumulate) {
+    if (f_ac) {
       IO::unpack(va[u], r);
 #pragma unroll
       for (int e = 0; e < CPU; ++e) vu[e] += r[e];
     }
-    if (a.out_bits) {
+    if (f_ob) {
 #pragma unroll
       for (int e = 0; e < CPU; ++e) ob |= (vu[e] > 0.f ? 1u : 0u) << (u * CPU + e);
     }
     __builtin_amdgcn_raw_buffer_store_b128(IO::pack(vu), R.rY, offy, u * 16, 0);
   }
-  if (LEAN || a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, (LEAN && !a.out_bits) ? DG_OOB_OFF : boff, 0, 0);
+  if (F >= 0) { if (f_ob) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, boff, 0, 0); }
+  else if (LEAN || a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, (LEAN && !a.out_bits) ? DG_OOB_OFF : boff, 0, 0);
 }
 
 // ---- Epilogue of the row-tiled kernels (generic / fast / im2col): like halo_epilogue below, every tensor is
@@ -663,6 +675,8 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       mbv[h][i] = epi64_bits<false>(a, R, ok ? (unsigned)(((rel0 + i * rowp) * ldb + (cb64 >> 6) * 4 + g) * 2) : DG_OOB_OFF);
     }
   }
+  auto run = [&](auto tag) {
+  constexpr int F = decltype(tag)::value;
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     // permuted wave tile (perm64): the lane's four channel fragments are the 16 consecutive channels from cb16
@@ -682,11 +696,26 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       const bool ok = cok && ty0 + wp * 4 + i < a.Hg;
       const int rel = rel0 + i * rowp;
       const int pix = rel + pj0;
-      epi64_pixel<T, false>(a, R, acc[4 * h][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i], bias,
+      epi64_pixel<T, (F >= 0), F>(a, R, acc[4 * h][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i], bias,
                             ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
                             ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
                             ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[h][i]);
     }
+  }
+  };
+  // the flag combinations the train step launches most get straight-line instances; everything else the general one
+  const int key = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.r1 ? 8 : 0) | (a.r2 ? 16 : 0) | (a.mask ? 32 : 0) |
+                  (a.accumulate ? 64 : 0);
+  switch (key) {
+    case 0: run(std::integral_constant<int, 0>{}); break;      // plain / bias only (data gradients without a mask)
+    case 1: run(std::integral_constant<int, 1>{}); break;      // bias + LeakyReLU (generator dense-block convs)
+    case 2: run(std::integral_constant<int, 2>{}); break;      // 1-bit mask (critic data gradients, penalty tangent forward)
+    case 5: run(std::integral_constant<int, 5>{}); break;      // LeakyReLU + out_bits (critic forward)
+    case 8: run(std::integral_constant<int, 8>{}); break;      // residual (generator dense-block output)
+    case 24: run(std::integral_constant<int, 24>{}); break;    // two residuals (RRDB output)
+    case 32: run(std::integral_constant<int, 32>{}); break;    // activation mask (data gradients of the narrow configs)
+    case 64: run(std::integral_constant<int, 64>{}); break;    // accumulate (dense-block data gradients)
+    default: run(std::integral_constant<int, -1>{}); break;
   }
 }
 
