@@ -745,6 +745,16 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
     int nb = cur + 2; if (nb >= 3) nb -= 3;
     if (ahead) issue(nb, ks + 2);            // buffer (ks + 2) % 3 was last read in step ks - 1, behind that step's barrier
     const unsigned char* sb = wgw_dsm + cur * BUFB;
+    // input fragments are read one tap ahead of the MFMAs that use them (two fragment registers sets of 4): the LDS latency
+    // of tap s+1 runs under the four MFMAs of tap s instead of in front of its own
+    auto read_fb = [&](int s, int kk) {
+      const unsigned char* pb = sb + bxs[s] + kk * 16 * XK * ROWB;
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb));
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + 4 * XK * ROWB));
+      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8_t, v);
+    };
+    bf16x8_t fb = read_fb(0, 0);
 #pragma unroll
     for (int kk = 0; kk < KP / 16; ++kk) {
       bf16x8_t fa[4];
@@ -766,14 +776,15 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
       }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        const unsigned char* pb = sb + bxs[s] + kk * 16 * XK * ROWB;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + 4 * XK * ROWB));
-        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, v);
+        bf16x8_t fbn = fb;
+        const bool last = s == 2 && kk == KP / 16 - 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!last) fbn = read_fb(s == 2 ? 0 : s + 1, s == 2 ? kk + 1 : kk);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < 4; ++f) acc[s][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f], fb, acc[s][f], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);       // 192 accumulator registers: keep one input fragment live at a time
+        __builtin_amdgcn_sched_barrier(0);       // 192 accumulator registers: one input fragment in use, one in flight
+        fb = fbn;
       }
     }
     wait_older(ahead);
