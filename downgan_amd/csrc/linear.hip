@@ -30,29 +30,44 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const T* __restrict__ x, l
   constexpr int EPC = DT<T>::EPC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long gw = (long long)blockIdx.x * 4 + wave;
-  const long long k0 = gw * kpw;
-  const long long k1 = k0 + kpw < K ? k0 + kpw : K;
   const int l15 = lane & 15, g = lane >> 4;
   f32x4_t acc[NO][NB];
 #pragma unroll
   for (int j = 0; j < NO; ++j)
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  for (long long k = k0 + g * EPC; k < k1; k += 4 * EPC) {
-    uint4 fb[NB], fa[NO];
+  // K is dealt to the waves in INTERLEAVED blocks of UK * 32 (bf16) elements: at any moment the whole grid reads one
+  // neighbourhood of each weight row (2048 waves x 256 B = 512 KB runs per row) instead of 2048 x 112 scattered streams
+  // -- contiguous per-wave ranges kept the weight stream at 1.7 TB/s (DRAM page misses).  UK k-blocks' loads go out
+  // before the first MFMA.
+  constexpr int UK = NO * NB <= 14 ? 4 : 2;
+  const long long blk = (long long)UK * 4 * EPC;
+  for (long long kb = gw * blk; kb < K; kb += kpw * blk) {          // kpw = number of waves in the grid
+    const long long k = kb + g * EPC;
+    uint4 fb[UK][NB], fa[UK][NO];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int b = 16 * i + l15;
-      const bool ok = b < B;
-      uint4 v = *reinterpret_cast<const uint4*>(x + (ok ? (long long)b * ldx + k : 0ll));
-      fb[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    for (int u = 0; u < UK; ++u) {
+      const long long ku = k + u * 4 * EPC;
+      const bool kin = ku < K;                        // K % (4 * EPC) == 0: a k-block is inside the range or past it
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int b = 16 * i + l15;
+        const bool ok = b < B && kin;
+        uint4 v = *reinterpret_cast<const uint4*>(x + (ok ? (long long)b * ldx + ku : 0ll));
+        fb[u][i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < NO; ++j) {
+        uint4 v = *reinterpret_cast<const uint4*>(w + (long long)(16 * j + l15) * ldw + (kin ? ku : k));
+        fa[u][j] = make_uint4(kin ? v.x : 0u, kin ? v.y : 0u, kin ? v.z : 0u, kin ? v.w : 0u);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < NO; ++j) fa[j] = *reinterpret_cast<const uint4*>(w + (long long)(16 * j + l15) * ldw + k);
+    for (int u = 0; u < UK; ++u)
 #pragma unroll
-    for (int j = 0; j < NO; ++j)
+      for (int j = 0; j < NO; ++j)
 #pragma unroll
-      for (int i = 0; i < NB; ++i) MmaL<T>::run(fa[j], fb[i], acc[j][i]);
+        for (int i = 0; i < NB; ++i) MmaL<T>::run(fa[u][j], fb[u][i], acc[j][i]);
   }
 #pragma unroll
   for (int j = 0; j < NO; ++j)
@@ -71,11 +86,13 @@ template <typename T, int NB, int NO>
 static int lin_fwd_launch(const T* x, long long ldx, const T* w, long long ldw, float* y, int ldy, int B, int O,
                           long long K, hipStream_t st) {
   constexpr int EPC = DT<T>::EPC;
-  const long long unit = 4 * EPC * 8;
-  long long kpw = (K + 2047) / 2048;
-  kpw = (kpw + unit - 1) / unit * unit;
-  const long long nw = (K + kpw - 1) / kpw;
-  const unsigned nb = (unsigned)((nw + 3) / 4);
+  constexpr int UK = NO * NB <= 14 ? 4 : 2;
+  const long long blk = (long long)UK * 4 * EPC;
+  long long nw = (K + blk - 1) / blk;                  // one interleaved block stream per wave, at most 2048 waves
+  if (nw > 2048) nw = 2048;
+  nw = (nw + 3) / 4 * 4;
+  const long long kpw = nw;
+  const unsigned nb = (unsigned)(nw / 4);
   hipLaunchKernelGGL((lin_fwd_kernel<T, NB, NO>), dim3(nb), dim3(256), 0, st, x, ldx, w, ldw, y, ldy, B, O, K, kpw);
   return dg_check_launch();
 }
@@ -179,7 +196,7 @@ extern "C" int dg_linear_dx(int dtype, int out_dtype, const float* dy, int ldo, 
   if (B <= 0 || O <= 0 || O > 128 || K <= 0 || K % 8 || ldw % 8 || lddx % 8) return DG_ERR_BAD_SHAPE;
   if (mask && ldmask % 8) return DG_ERR_BAD_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  constexpr int BG = 8;
+  constexpr int BG = 16;             // batch rows per pass over W: a batch of 32 streams the matrix twice (was 4x with 8)
   const int epc = dtype == DG_F32 ? 4 : 8;
   dim3 grid((unsigned)((K / epc + 255) / 256), (unsigned)((B + BG - 1) / BG));
   if (dtype == DG_F32 && out_dtype == DG_F32)
