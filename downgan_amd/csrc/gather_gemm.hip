@@ -1065,7 +1065,9 @@ static bool regroup_taps_by_plane(GGArgs& a) {
 // One barrier per step, at its top:  BARRIER | DMA W[s+2] -> slot s&1 | mma(k0) | read k0 of s+1 | mma(k1) | read k1 of s+1.
 // S2: stride-2 forward over the four parity planes of the input (see gg_halo128_kernel): K loop over (plane, channel block)
 // pairs with 1 / 2 / 2 / 4 taps, the plane's patch gathered with stride 2.
-template <typename T, bool S2>
+// PS: pixel-shuffled source (data gradient of an up-sampling conv): virtual pixel (y, x), channel quarter q = stored pixel
+// (2y + (q >> 1), 2x + (q & 1)); a 64-channel block lies inside one quarter, so its patch is a stride-2 gather like S2's.
+template <typename T, bool S2, bool PS = false>
 __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int tiles_x, int tiles_y) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int ES = (int)sizeof(T);
@@ -1089,7 +1091,8 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   const int c0 = tile_c * BC;
   const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0,32)
   const int sy_base = S2 ? (ty0 > 0 ? 2 * (ty0 - 1) : 0) : (ty0 - 1 > 0 ? ty0 - 1 : 0);
-  const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
+  const char* Xb = PS ? reinterpret_cast<const char*>(a.x) + ((long long)img * 2 * a.Hs + 2 * sy_base) * (2 * a.Ws) * a.ldx * ES
+                      : reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
   const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
   const int l15 = lane & 15, g = lane >> 4;
   const int ncbr = a.cch / KC;                    // real channel blocks
@@ -1115,7 +1118,10 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   auto load_patch = [&](int vcb) {
     const int plane = plane_of(vcb), cb = vcb - plane * ncbr;
     const int ppy = plane >> 1, ppx = plane & 1;
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+    const int psq = PS ? (cb * KC) / a.cps_src_chunks : 0;                 // channel quarter of this block
+    const int psy = psq >> 1, psx = psq & 1;
+    const long long cboff = PS ? (long long)(cb * KC - psq * a.cps_src_chunks) * EPC * ES : (long long)cb * KC * EPC * ES;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + cboff), 0, (int)DG_OOB_OFF, 0x00020000);
     int r0v = r0;
     asm volatile("" : "+v"(r0v));
 #pragma unroll
@@ -1124,7 +1130,9 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
       const int py = pr / PW, px = pr - py * PW;
       const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
       const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-      const unsigned off = ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
+      const unsigned off = !ok ? DG_OOB_OFF
+                           : PS ? (unsigned)(((2 * (sy - sy_base) + psy) * (2 * a.Ws) + 2 * sx + psx) * a.ldx * ES) + cc * 16
+                                : (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16;
       rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1272,12 +1280,12 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
 #endif
 }
 
-template <typename T, bool S2>
+template <typename T, bool S2, bool PS = false>
 static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
   constexpr int LDS_BYTES = 324 * 144 + 2 * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo4w_kernel<T, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo4w_kernel<T, S2, PS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return DG_ERR_LAUNCH;
     attr_set = true;
   }
@@ -1285,7 +1293,7 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
   a.nct = (unsigned)((a.Nout + 127) / 128);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
   g_last_kinds |= 8;
-  hipLaunchKernelGGL((gg_halo4w_kernel<T, S2>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL((gg_halo4w_kernel<T, S2, PS>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, tiles_x, tiles_y);
   return dg_check_launch();
 }
 
@@ -1675,6 +1683,11 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
     if (!no_ct && a.cch == 16 && a.Nout % 128 == 0 && a.Nout >= 256 && a.Nout <= 1024) return gg_launch_halo128<T, 2>(a, N, st);
     if (a.cch % 16 == 0) return gg_launch_halo128<T, 0>(a, N, st);
   }
+  // pixel-shuffled sources (data gradients of the up-sampling convs) whose channel quarters hold whole 64-channel blocks
+  static const bool no4w_ps = no4w || getenv("DG_GG_NO4WPS") != nullptr;
+  if (!no_halo && !no4w_ps && a.sy_mul == 1 && a.sx_mul == 1 && a.src_ps && a.cps_src_chunks % 8 == 0 && a.cch % 8 == 0 && a.Nout > 64 &&
+      a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 && a.Hs == a.Hg && a.Ws == a.Wg)
+    return gg_launch_halo4w<T, false, true>(a, N, st);
   static const bool no_s2halo = getenv("DG_GG_NOS2HALO") != nullptr;
   if (!no_halo && !no_s2halo && a.sy_mul == 2 && a.sx_mul == 2 && !a.src_ps && a.cch % 16 == 0 && a.Nout > 64 && a.Hg >= 8 &&
       a.Wg >= 8 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1)
