@@ -998,8 +998,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
   STAMP(tL1);
 #endif
 
-  // (an LDS-staged epilogue with 16-byte row stores measured 0.8 % slower end to end: the tail is bound by the
-  // chip-wide write burst, and the staging adds two barriers)
+  // (16-byte stores come from the perm64 channel order, not from staging the tile through LDS: see epi64_pixel)
   if constexpr (!CT) halo_epilogue<T, 1>(a, acc, img, ty0, tx0, c0, wp, wc, l15, g);
 #ifdef DG_STAMP
   STAMP(tX);
@@ -1059,7 +1058,8 @@ static bool regroup_taps_by_plane(GGArgs& a) {
 // Four-wave halo kernel, TWO workgroups per CU.  Same tile as gg_halo128_kernel (16x16 pixels x 128 output channels) but
 // 64-channel K-steps, so patch (324 x 144 B) + two 16-KB weight slots = 78 KB and a second, independent workgroup shares
 // the CU: its tap-step loop runs while this one sits in its prologue (exposed patch latency) or in its store-bound
-// epilogue (~14k cycles per tile at ~2.2 TB/s chip-wide), which is where 9..18-step tiles lose 30-50 % of their time; and
+// epilogue (then ~14k cycles per tile; 7-11k since the 16-byte, flag-specialised epilogue), which is where 9..18-step tiles
+// lose 30-50 % of their time; and
 // the two waves of a SIMD now belong to different workgroups (no shared barrier, no lock-step).  Each wave owns 4 tile
 // rows x all 128 channels (8 x 4 accumulator fragments, 3 LDS fragment reads per 8 MFMAs instead of 4).
 // One barrier per step, at its top:  BARRIER | DMA W[s+2] -> slot s&1 | mma(k0) | read k0 of s+1 | mma(k1) | read k1 of s+1.
