@@ -4,7 +4,8 @@
 Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 is launched by torch.distributed.run,
 one rank per GPU over RCCL).  A "step" is one minibatch through the critic iteration plus the
 generator iteration when step % 5 == 0 (reference DoWnGAN/GAN/wasserstein.py:131-147; the metrics
-pass :140 is excluded).  Workload at N=1 = BASELINE.json configs[1]: batch 32 per GPU, 2-channel
+pass :140 is excluded); the timed region always opens with a generator step, so K timed steps hold ceil(K/5)
+generator iterations whatever --steps / --warmup are.  Workload at N=1 = BASELINE.json configs[1]: batch 32 per GPU, 2-channel
 128x128 -> 1024x1024 tiles, filters 128, 16 RRDBs, bf16 storage + bf16 MFMA with fp32 accumulate,
 fp32 master weights / Adam.  Inputs are synthetic N(0,1) tiles resident in HBM in native NHWC layout
 before the timed region.  Rank 0 prints ONE JSON line.
@@ -171,6 +172,13 @@ def main():
 
     for s in range(args.warmup):
         eng.train_step(xc, xf, alphas[s])
+    # The generator runs every `critic_iterations`-th step.  Align the step counter so that the timed region OPENS with a
+    # generator step: K timed steps then contain ceil(K / critic_iterations) generator iterations for every --steps /
+    # --warmup combination -- never fewer than the long-run share (a 3-step region after 2 warm-up steps would otherwise
+    # hold none and read 25 % too fast).
+    ci = eng.hp.critic_iterations
+    eng.num_steps = -(-eng.num_steps // ci) * ci
+    gen_steps_timed = -(-args.steps // ci)
     complete_updates()
     if dist:
         dist.barrier()
@@ -240,7 +248,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: batch {B}/GPU (global {B * world}), {cin}ch {S}x{S}->{8 * S}x{8 * S}, "
                                    f"filters {F_}, {nrb} RRDBs, WGAN-GP critic step every step + generator step every 5th",
-                       "parallelism": f"dp{world}", "alg_tflop_per_sample_step": round(w_step / 1e12, 4)},
+                       "parallelism": f"dp{world}", "alg_tflop_per_sample_step": round(w_step / 1e12, 4),
+                       "generator_steps_in_timed_region": gen_steps_timed},
             "step_mfma_frac": round(w_step * value / world / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4),
             "losses": {k: scal[k] for k in ("critic_loss", "gp_ret", "g_loss") if k in scal},
             "roofline": roofline, "critic_conv_stack": critic_stack, "kernels": kernels,
