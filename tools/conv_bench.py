@@ -30,10 +30,12 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
     ap.add_argument("--layers", default="", help="comma-separated substrings of layer names to run")
+    ap.add_argument("--nscale", type=int, default=1, help="multiply every layer's batch (the table uses small batches)")
     args = ap.parse_args()
     o = HipOps(args.dtype)
     g = torch.Generator().manual_seed(0)
     for name, N, H, ci, co, st, ps in LAYERS:
+        N *= args.nscale
         if args.layers and not any(k in name for k in args.layers.split(',')):
             continue
         cv = Conv(N, H, H, ci, co, st, ps, cin_real=(2 if ci == 16 and st == 1 else 0))
