@@ -1335,32 +1335,35 @@ __global__ __launch_bounds__(256, 2) void gg_halo16_kernel(const GGArgs a, int t
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  for (int cb = 0; cb < ncb; ++cb) {
-    u32x4_t rp[NPL], rw[NWL];
-    {
-      __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+  // the next block's patch and weights are fetched into registers while the current block computes (the kernel is
+  // HBM-latency-bound: with the loads issued at the top of their own block every block waited a full memory round trip)
+  u32x4_t rp[NPL], rw[NWL];
+  auto load_block = [&](int cb) {
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        const int pr = r0 + 32 * i;
-        const int py = pr / PW, px = pr - py * PW;
-        const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
-        const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-        const unsigned off = ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
-        rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
-      }
-      __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < NWL; ++i) {
-        const int wr = r0 + 32 * i;                 // row = tap * 16 + channel
-        const int t = wr >> 4, n = wr & 15;
-        unsigned off = DG_OOB_OFF;
-        if (wr < WROWS && t < ntaps && n < a.Nout) {
-          const unsigned code = t < 8 ? (unsigned)((a.tap_lo >> (8 * t)) & 0xffull) : (a.tap_hi & 0xffu);
-          off = (unsigned)(((long long)n * a.ldw + (long long)(code >> 4) * a.Cred) * ES) + cc * 16;
-        }
-        rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rwd, off, 0, 0);
-      }
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0 + 32 * i;
+      const int py = pr / PW, px = pr - py * PW;
+      const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+      const unsigned off = ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16 : DG_OOB_OFF;
+      rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
     }
+    __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc((void*)(Wb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int wr = r0 + 32 * i;                 // row = tap * 16 + channel
+      const int t = wr >> 4, n = wr & 15;
+      unsigned off = DG_OOB_OFF;
+      if (wr < WROWS && t < ntaps && n < a.Nout) {
+        const unsigned code = t < 8 ? (unsigned)((a.tap_lo >> (8 * t)) & 0xffull) : (a.tap_hi & 0xffu);
+        off = (unsigned)(((long long)n * a.ldw + (long long)(code >> 4) * a.Cred) * ES) + cc * 16;
+      }
+      rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rwd, off, 0, 0);
+    }
+  };
+  load_block(0);
+  for (int cb = 0; cb < ncb; ++cb) {
     __syncthreads();                                // everybody is done with the previous block's tiles
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
@@ -1373,6 +1376,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo16_kernel(const GGArgs a, int t
       if (wr < WROWS) *reinterpret_cast<uint4*>(s_w + wr * PITCH + cc * 16) = __builtin_bit_cast(uint4, rw[i]);
     }
     __syncthreads();
+    if (cb + 1 < ncb) load_block(cb + 1);
     for (int t = 0; t < ntaps; ++t) {
       const unsigned code = t < 8 ? (unsigned)((a.tap_lo >> (8 * t)) & 0xffull) : (a.tap_hi & 0xffu);
       const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
