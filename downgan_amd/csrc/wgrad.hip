@@ -329,6 +329,21 @@ static int wg_launch_im2col(WGArgs& a, hipStream_t st) {
   return dg_check_launch();
 }
 
+// Split-K factor of a weight-gradient launch: ntiles x splits workgroups, the LARGEST count that still fits `target` (a whole
+// number of rounds of the chip's resident-workgroup slots, or the atomics budget `cap` if that is smaller).  Rounding the
+// split count up instead spilled a few workgroups into an extra, nearly empty round (96 tiles x 22 splits = 2112 = 4.125
+// rounds of 512 slots: -5 % against 1536 or 3072).  Returns the split count and the pixels per workgroup (multiple of 64).
+static int wg_pick_splits(int ntiles, long long target, long long cap, int Mpix, int* ppb) {
+  if (cap < 512) cap = 512;
+  if (target > cap) target = cap;
+  int splits = (int)(target / ntiles);
+  const int max_splits = (Mpix + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  *ppb = ((Mpix + splits - 1) / splits + 63) / 64 * 64;
+  return (Mpix + *ppb - 1) / *ppb;
+}
+
 template <typename T>
 static int wg_launch(WGArgs& a, hipStream_t st) {
   const bool big_co = a.Cout > 64, big_ci = a.Cin > 64;
@@ -340,15 +355,8 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   // every workgroup ends with a 64-KB (tile) atomic accumulate at ~1.3 TB/s chip-wide: cap the workgroup count so
   // that this traffic stays below ~1/4 of the MFMA time (estimated at 600 TFLOP/s), but keep >= 512 workgroups
   const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
-  long long cap = (long long)(flops * 5.4e-4 / (bco * bci * 4.0));
-  if (cap < 512) cap = 512;
-  const int tb = target_blocks < cap ? target_blocks : (int)cap;
-  int splits = (tb + ntiles - 1) / ntiles;
-  const int max_splits = (a.Mpix + 255) / 256;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  a.ppb = ((a.Mpix + splits - 1) / splits + 63) / 64 * 64;
-  splits = (a.Mpix + a.ppb - 1) / a.ppb;
+  const long long cap = (long long)(flops * 5.4e-4 / (bco * bci * 4.0));
+  const int splits = wg_pick_splits(ntiles, target_blocks, cap, a.Mpix, &a.ppb);
   dim3 grid(ntiles, splits);
   static const bool no_rowstep = getenv("DG_WG_GENERIC") != nullptr;
   const bool rs = !no_rowstep && a.Wo % 32 == 0;
@@ -584,15 +592,8 @@ static int wg3_launch(WGArgs& a, hipStream_t st) {
   a.nci_t = (a.Cin + BCI - 1) / BCI;
   const int ntiles = nco_t * 3 * a.nci_t;
   const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
-  long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
-  if (cap < 512) cap = 512;
-  const int tb = 2304 < cap ? 2304 : (int)cap;
-  int splits = (tb + ntiles - 1) / ntiles;
-  const int max_splits = (a.Mpix + 255) / 256;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  a.ppb = ((a.Mpix + splits - 1) / splits + 63) / 64 * 64;
-  splits = (a.Mpix + a.ppb - 1) / a.ppb;
+  const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
+  const int splits = wg_pick_splits(ntiles, 2304, cap, a.Mpix, &a.ppb);             // 3 rounds of 768 slots (3 per CU)
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
   const int lds = 2 * (32 * (BCO + PADE) + 34 * (BCI + PADE)) * (int)sizeof(T);
   static bool attr = false;
@@ -823,15 +824,9 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
   a.nci_t = (a.Cin + BCI - 1) / BCI;
   const int ntiles = nco_t * 3 * a.nci_t;
   const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
-  long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
-  if (cap < 512) cap = 512;
-  const int tb = 2048 < cap ? 2048 : (int)cap;                                 // 512 workgroup slots (2 per CU)
-  int splits = (tb + ntiles - 1) / ntiles;
-  const int max_splits = (a.Mpix + 255) / 256;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  a.ppb = ((a.Mpix + splits - 1) / splits + 63) / 64 * 64;
-  splits = (a.Mpix + a.ppb - 1) / a.ppb;
+  const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
+  static const int tb_env = getenv("DG_WG_TB") ? atoi(getenv("DG_WG_TB")) : 1536;
+  const int splits = wg_pick_splits(ntiles, tb_env, cap, a.Mpix, &a.ppb);           // 3 rounds of 512 slots (2 per CU)
   constexpr int lds = 3 * (32 * 256 + (S2 ? 68 : 36) * 256);
   static bool attr = false;
   if (!attr && lds > 65536) {
