@@ -311,24 +311,6 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
     }
 }
 
-template <typename T>
-static int wg_launch_im2col(WGArgs& a, hipStream_t st) {
-  const bool big_co = a.Cout > 64;
-  const int bco = big_co ? 128 : 64;
-  const int nco_t = (a.Cout + bco - 1) / bco;
-  int splits = (2304 + nco_t - 1) / nco_t;
-  const int max_splits = (a.Mpix + 2047) / 2048;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  a.ppb = ((a.Mpix + splits - 1) / splits + 31) / 32 * 32;
-  splits = (a.Mpix + a.ppb - 1) / a.ppb;
-  dim3 grid(nco_t, splits);
-  constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
-  if (big_co) hipLaunchKernelGGL((wg_kernel<T, 128, 64, true, 32, true>), grid, dim3(256), 2 * 32 * (128 + 64 + 2 * PADE) * (int)sizeof(T), st, a);
-  else hipLaunchKernelGGL((wg_kernel<T, 64, 64, true, 32, true>), grid, dim3(256), 2 * 32 * (64 + 64 + 2 * PADE) * (int)sizeof(T), st, a);
-  return dg_check_launch();
-}
-
 // Split-K factor of a weight-gradient launch: ntiles x splits workgroups, the LARGEST count that still fits `target` (a whole
 // number of rounds of the chip's resident-workgroup slots, or the atomics budget `cap` if that is smaller).  Rounding the
 // split count up instead spilled a few workgroups into an extra, nearly empty round (96 tiles x 22 splits = 2112 = 4.125
@@ -344,6 +326,36 @@ static int wg_pick_splits(int ntiles, long long target, long long cap, int Mpix,
   return (Mpix + *ppb - 1) / *ppb;
 }
 
+// resident workgroups per CU of a kernel instance (LDS- or register-limited), for sizing launches in whole rounds
+template <typename K>
+static int wg_resident(K kernel, int lds_bytes) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, (size_t)lds_bytes) != hipSuccess || n < 1) n = 2;
+  return n;
+}
+
+template <typename T>
+static int wg_launch_im2col(WGArgs& a, hipStream_t st) {
+  const bool big_co = a.Cout > 64;
+  const int bco = big_co ? 128 : 64;
+  const int nco_t = (a.Cout + bco - 1) / bco;
+  constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
+  const int lds = 2 * 32 * (bco + 64 + 2 * PADE) * (int)sizeof(T);
+  static int occ[2] = {0, 0};
+  if (!occ[big_co]) occ[big_co] = big_co ? wg_resident(wg_kernel<T, 128, 64, true, 32, true>, lds) : wg_resident(wg_kernel<T, 64, 64, true, 32, true>, lds);
+  // two whole rounds of the resident slots (2304 workgroups on 5 x 256 slots were 1.8 rounds)
+  int splits = 2 * 256 * occ[big_co] / nco_t;
+  const int max_splits = (a.Mpix + 2047) / 2048;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.ppb = ((a.Mpix + splits - 1) / splits + 31) / 32 * 32;
+  splits = (a.Mpix + a.ppb - 1) / a.ppb;
+  dim3 grid(nco_t, splits);
+  if (big_co) hipLaunchKernelGGL((wg_kernel<T, 128, 64, true, 32, true>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((wg_kernel<T, 64, 64, true, 32, true>), grid, dim3(256), lds, st, a);
+  return dg_check_launch();
+}
+
 template <typename T>
 static int wg_launch(WGArgs& a, hipStream_t st) {
   const bool big_co = a.Cout > 64, big_ci = a.Cin > 64;
@@ -351,20 +363,18 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   const int nco_t = (a.Cout + bco - 1) / bco;
   a.nci_t = (a.Cin + bci - 1) / bci;
   const int ntiles = nco_t * 9 * a.nci_t;
-  static const int target_blocks = getenv("DG_WG_BLOCKS") ? atoi(getenv("DG_WG_BLOCKS")) : 2304;   // 3 resident workgroups x 256 CUs x 3 rounds
+  static const int target_blocks = getenv("DG_WG_BLOCKS") ? atoi(getenv("DG_WG_BLOCKS")) : 0;   // 0: whole rounds of the resident slots
   // every workgroup ends with a 64-KB (tile) atomic accumulate at ~1.3 TB/s chip-wide: cap the workgroup count so
   // that this traffic stays below ~1/4 of the MFMA time (estimated at 600 TFLOP/s), but keep >= 512 workgroups
   const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
   const long long cap = (long long)(flops * 5.4e-4 / (bco * bci * 4.0));
-  const int splits = wg_pick_splits(ntiles, target_blocks, cap, a.Mpix, &a.ppb);
-  dim3 grid(ntiles, splits);
   static const bool no_rowstep = getenv("DG_WG_GENERIC") != nullptr;
   const bool rs = !no_rowstep && a.Wo % 32 == 0;
   // 64-pixel K-steps halve the barrier count but also the resident workgroups (LDS): measured equal to 32-pixel
   // steps, so they are opt-in.  256x128 / 128x256 tiles (each wave 128x64, 2 workgroups per CU, 25 % fewer staged bytes
   // per flop) were measured 8-20 % SLOWER than 128x128 with 3 workgroups per CU and are not built.
   static const bool want_kp64 = getenv("DG_WG_KP64") != nullptr;
-  const bool kp64 = rs && want_kp64 && a.Wo % 64 == 0 && a.ppb % 64 == 0 && sizeof(T) == 2;
+  const bool kp64 = rs && want_kp64 && a.Wo % 64 == 0 && sizeof(T) == 2;                 // (ppb is a multiple of 64)
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
 #define WG_LAUNCH1(BCO, BCI, RS, KPV)                                                                 \
   do {                                                                                                \
@@ -375,6 +385,12 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DG_ERR_LAUNCH; \
       attr = true;                                                                                    \
     }                                                                                                 \
+    static int occ = 0;                                                                               \
+    if (!occ) occ = wg_resident(wg_kernel<T, BCO, BCI, RS, KPV>, lds);                                \
+    /* 3 rounds of the resident slots, 2 when more than 3 workgroups share a CU */                    \
+    const long long target = target_blocks ? target_blocks : (long long)(occ > 3 ? 2 : 3) * 256 * occ; \
+    const int splits = wg_pick_splits(ntiles, target, cap, a.Mpix, &a.ppb);                           \
+    dim3 grid(ntiles, splits);                                                                        \
     hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, RS, KPV>), grid, dim3(256), lds, st, a);               \
   } while (0)
 #define WG_LAUNCH(BCO, BCI)                                                                           \
