@@ -20,7 +20,8 @@ class Epilogue(C.Structure):
                 ("r1", C.c_void_p), ("ldr1", C.c_int64), ("s1", C.c_float),
                 ("r2", C.c_void_p), ("ldr2", C.c_int64), ("s2", C.c_float),
                 ("mask", C.c_void_p), ("ldmask", C.c_int64), ("mask_slope", C.c_float),
-                ("accumulate", C.c_int), ("mask_bits", C.c_void_p), ("out_bits", C.c_void_p)]
+                ("accumulate", C.c_int), ("mask_bits", C.c_void_p), ("out_bits", C.c_void_p),
+                ("mask_c0", C.c_int), ("mask_last", C.c_int)]
 
 
 class ConvGeom(C.Structure):

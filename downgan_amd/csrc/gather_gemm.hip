@@ -43,6 +43,7 @@ struct GGArgs {
   int has_act, accumulate;
   float act_slope, s1, s2, mask_slope;
   unsigned nwg, nct;
+  int mask_c0, mask_last;                      // dg_epilogue: mask for channels >= mask_c0 only, applied after the accumulate
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -144,7 +145,7 @@ __device__ __forceinline__ unsigned epi64_bits(const GGArgs& a, const EpiRes& R,
 template <typename T, bool LEAN, int F = -1>
 __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, const f32x4_t& f0, const f32x4_t& f1, const f32x4_t& f2,
                                             const f32x4_t& f3, const float (&bias)[16], unsigned offy, unsigned off1, unsigned off2,
-                                            unsigned offm, unsigned boff, unsigned mb) {
+                                            unsigned offm, unsigned boff, unsigned mb, bool mask_on) {
   typedef EpiV<T> IO;
   constexpr int NU = IO::NU, CPU = IO::CPU;
   u32x4_t v1[NU], v2[NU], vm[NU], va[NU];
@@ -154,7 +155,9 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
   const bool f_ob = F < 0 ? a.out_bits != nullptr : (F & 4) != 0;
   const bool f_r1 = F < 0 ? !LEAN && a.r1 != nullptr : (F & 8) != 0;
   const bool f_r2 = F < 0 ? !LEAN && a.r2 != nullptr : (F & 16) != 0;
-  const bool f_mk = F < 0 ? !LEAN && a.mask != nullptr : (F & 32) != 0;
+  // mask_on (run-time path): the caller's "this lane's channels are masked" (a.mask && channel >= a.mask_c0)
+  const bool f_mk = F < 0 ? !LEAN && mask_on && !a.mask_last : (F & 32) != 0;       // mask before the accumulate
+  const bool f_ml = F < 0 ? !LEAN && mask_on && a.mask_last != 0 : (F & 128) != 0;  // mask after it
   const bool f_ac = F < 0 ? !LEAN && a.accumulate != 0 : (F & 64) != 0;
   // LEAN runs inside a tile loop whose memory operations must be unconditional (see gg_im2col_kernel): absent bit-mask
   // operands become out-of-range offsets (the load returns 0, the store is dropped)
@@ -162,7 +165,7 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
   for (int u = 0; u < NU; ++u) {
     if (f_r1) v1[u] = __builtin_amdgcn_raw_buffer_load_b128(R.r1, off1, u * 16, 0);
     if (f_r2) v2[u] = __builtin_amdgcn_raw_buffer_load_b128(R.r2, off2, u * 16, 0);
-    if (f_mk) vm[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rm, offm, u * 16, 0);
+    if (f_mk || f_ml) vm[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rm, offm, u * 16, 0);
     if (f_ac) va[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rY, offy, u * 16, 0);
   }
   float v[16];
@@ -205,6 +208,11 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
       IO::unpack(va[u], r);
 #pragma unroll
       for (int e = 0; e < CPU; ++e) vu[e] += r[e];
+    }
+    if (f_ml) {
+      IO::unpack(vm[u], r);
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) vu[e] *= leaky_grad(r[e], a.mask_slope);
     }
     if (f_ob) {
 #pragma unroll
@@ -274,7 +282,7 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
       epi64_pixel<T, LEAN>(a, R, acc[0][i], acc[1][i], acc[2][i], acc[3][i], bias,
                            ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
                            ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
-                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i]);
+                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i], a.mask && cb16 >= a.mask_c0);
     }
     return;
   }
@@ -325,6 +333,7 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
       if (!LEAN && a.mask) vm[j] = IO::load(rm, ok ? (unsigned)((pix * ldm + cc[j]) * ES) : DG_OOB_OFF);
       if (!LEAN && a.accumulate) va[j] = IO::load(rY, oyv[j]);
     }
+    const int cj0 = c0 + wc * WC + 4 * g;           // fragment j covers channels cj0 + 16 j .. + 3 (mask_c0 is a multiple of 16)
 #pragma unroll
     for (int j = 0; j < FC; ++j) {
       float v[4] = {acc[j][i][0] + bias[j].x, acc[j][i][1] + bias[j].y, acc[j][i][2] + bias[j].z, acc[j][i][3] + bias[j].w};
@@ -343,7 +352,8 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
       }
-      if (!LEAN && a.mask) {
+      const bool mask_j = !LEAN && a.mask && cj0 + 16 * j >= a.mask_c0;
+      if (mask_j && !a.mask_last) {
         IO::unpack(vm[j], r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
@@ -356,6 +366,11 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
         IO::unpack(va[j], r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      if (mask_j && a.mask_last) {
+        IO::unpack(vm[j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
       }
       if (a.out_bits) {
 #pragma unroll
@@ -675,10 +690,10 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       mbv[h][i] = epi64_bits<false>(a, R, ok ? (unsigned)(((rel0 + i * rowp) * ldb + (cb64 >> 6) * 4 + g) * 2) : DG_OOB_OFF);
     }
   }
-  auto run = [&](auto tag) {
+  auto run = [&](auto tag, auto htag) {
   constexpr int F = decltype(tag)::value;
-#pragma unroll
-  for (int h = 0; h < NH; ++h) {
+  constexpr int h = decltype(htag)::value;          // compile-time: acc[] must never be indexed dynamically
+  {
     // permuted wave tile (perm64): the lane's four channel fragments are the 16 consecutive channels from cb16
     const int cb16 = c0 + (wc + h) * 64 + 16 * g;
     const bool cok = cb16 < a.Nout && xok;
@@ -699,24 +714,33 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       epi64_pixel<T, (F >= 0), F>(a, R, acc[4 * h][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i], bias,
                             ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
                             ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
-                            ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[h][i]);
+                            ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[h][i], a.mask && cb16 >= a.mask_c0);
     }
   }
   };
-  // the flag combinations the train step launches most get straight-line instances; everything else the general one
-  const int key = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.r1 ? 8 : 0) | (a.r2 ? 16 : 0) | (a.mask ? 32 : 0) |
-                  (a.accumulate ? 64 : 0);
-  switch (key) {
-    case 0: run(std::integral_constant<int, 0>{}); break;      // plain / bias only (data gradients without a mask)
-    case 1: run(std::integral_constant<int, 1>{}); break;      // bias + LeakyReLU (generator dense-block convs)
-    case 2: run(std::integral_constant<int, 2>{}); break;      // 1-bit mask (critic data gradients, penalty tangent forward)
-    case 5: run(std::integral_constant<int, 5>{}); break;      // LeakyReLU + out_bits (critic forward)
-    case 8: run(std::integral_constant<int, 8>{}); break;      // residual (generator dense-block output)
-    case 24: run(std::integral_constant<int, 24>{}); break;    // two residuals (RRDB output)
-    case 32: run(std::integral_constant<int, 32>{}); break;    // activation mask (data gradients of the narrow configs)
-    case 64: run(std::integral_constant<int, 64>{}); break;    // accumulate (dense-block data gradients)
-    default: run(std::integral_constant<int, -1>{}); break;
-  }
+  // the flag combinations the train step launches most get straight-line instances; everything else the general one.
+  // Decoded per 64-channel half: the activation mask may start at channel mask_c0 (a multiple of 64 here, else general path)
+  const int key0 = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.r1 ? 8 : 0) | (a.r2 ? 16 : 0) | (a.accumulate ? 64 : 0);
+  auto dispatch = [&](auto htag) {
+    constexpr int h = decltype(htag)::value;
+    int key = key0;
+    if (a.mask) key = (a.mask_c0 & 63) ? -1 : (c0 + (wc + h) * 64 >= a.mask_c0 ? key0 | (a.mask_last ? 128 : 32) : key0);
+    switch (key) {
+      case 0: run(std::integral_constant<int, 0>{}, htag); break;      // plain / bias only (data gradients without a mask)
+      case 1: run(std::integral_constant<int, 1>{}, htag); break;      // bias + LeakyReLU (generator dense-block convs)
+      case 2: run(std::integral_constant<int, 2>{}, htag); break;      // 1-bit mask (critic data gradients, penalty tangent forward)
+      case 5: run(std::integral_constant<int, 5>{}, htag); break;      // LeakyReLU + out_bits (critic forward)
+      case 8: run(std::integral_constant<int, 8>{}, htag); break;      // residual (generator dense-block output)
+      case 24: run(std::integral_constant<int, 24>{}, htag); break;    // two residuals (RRDB output)
+      case 32: run(std::integral_constant<int, 32>{}, htag); break;    // activation mask (data gradients of the narrow configs)
+      case 64: run(std::integral_constant<int, 64>{}, htag); break;    // accumulate (dense-block data gradients)
+      case 128: run(std::integral_constant<int, 128>{}, htag); break;  // mask of the completed top slice (dense block, conv 5's data gradient)
+      case 192: run(std::integral_constant<int, 192>{}, htag); break;  // accumulate, then the completed slice's mask (convs 4..2)
+      default: run(std::integral_constant<int, -1>{}, htag); break;
+    }
+  };
+  dispatch(std::integral_constant<int, 0>{});
+  if constexpr (NH == 2) dispatch(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1428,7 +1452,8 @@ __global__ __launch_bounds__(256, 2) void gg_halo16_kernel(const GGArgs a, int t
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = v[e] * a.s2 + r[e];
     }
-    if (a.mask) {
+    const bool mask_on = a.mask && a.mask_c0 == 0;          // (<= 16 output channels: mask_c0 is 0 or excludes them all)
+    if (mask_on && !a.mask_last) {
       IO::unpack(IO::load(rm, ok ? (unsigned)((pix * (int)a.ldmask + cj) * ES) : DG_OOB_OFF), r);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
@@ -1437,6 +1462,11 @@ __global__ __launch_bounds__(256, 2) void gg_halo16_kernel(const GGArgs a, int t
       IO::unpack(IO::load(rY, oy), r);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    if (mask_on && a.mask_last) {
+      IO::unpack(IO::load(rm, ok ? (unsigned)((pix * (int)a.ldmask + cj) * ES) : DG_OOB_OFF), r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(r[e], a.mask_slope);
     }
     IO::store(v, rY, oy);
   }
@@ -1610,7 +1640,7 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void gg_im2col_kernel(const GGAr
       epi64_pixel<T, LEAN>(a, R, acc[0][i], acc[1][i], acc[2][i], acc[3][i], bias,
                            ok ? (unsigned)((rel * R.ldy + cb16) * ES) : DG_OOB_OFF, ok ? (unsigned)((rel * R.ld1 + cb16) * ES) : DG_OOB_OFF,
                            ok ? (unsigned)((rel * R.ld2 + cb16) * ES) : DG_OOB_OFF, ok ? (unsigned)((rel * R.ldm + cb16) * ES) : DG_OOB_OFF,
-                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i]);
+                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i], a.mask && cb16 >= a.mask_c0);
     }
     __syncthreads();
     publish();
@@ -1741,6 +1771,8 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     a.r1 = ep->r1; a.ldr1 = ep->ldr1; a.s1 = ep->s1;
     a.r2 = ep->r2; a.ldr2 = ep->ldr2; a.s2 = ep->s2;
     a.mask = ep->mask; a.ldmask = ep->ldmask; a.mask_slope = ep->mask_slope;
+    a.mask_c0 = ep->mask_c0; a.mask_last = ep->mask_last;
+    if (a.mask_c0 < 0 || a.mask_c0 % 16 || ((a.mask_c0 || a.mask_last) && !a.mask)) return DG_ERR_BAD_ARG;
     a.accumulate = ep->accumulate;
     a.mask_bits = ep->mask_bits; a.out_bits = ep->out_bits;
     // bit masks need 64-channel wave tiles (Nout >= 128 selects them in every dispatch path) and plain destinations

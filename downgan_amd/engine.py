@@ -501,13 +501,19 @@ class NativeGenerator:
                 pre = f"res_blocks.{i}.dense_blocks.{j}.b"
                 o.axpby(bw["d5"], go, RES_SCALE)          # d b5-out = 0.2 * d o
                 o.conv_wgrad(self.cv_b[4], slab, bw["d5"], GW(f"{pre}5.0"), db=GB(f"{pre}5.0"))
-                o.conv_dgrad(self.cv_b[4], bw["d5"], WD(f"{pre}5.0"), gs)
+                # Slice k of the gradient slab is complete once conv k+1's data gradient has added its share (conv 5's for
+                # k = 4); that launch multiplies the slice by LeakyReLU'(b_k output) in its own epilogue (mask_c0 / mask_last)
+                # instead of a separate read-modify-write pass over the slice.
+                o.conv_dgrad(self.cv_b[4], bw["d5"], WD(f"{pre}5.0"), gs, mask=slab, mask_slope=G_SLOPE, mask_c0=4 * F_, mask_last=True)
                 o.axpby(gs[..., :F_], gs[..., :F_], 1.0, go, 1.0)        # + identity path of o = 0.2*b5 + x
                 for k in range(4, 0, -1):
                     uk = gs[..., k * F_:(k + 1) * F_]
-                    o.mask_mul(uk, slab[..., k * F_:(k + 1) * F_], G_SLOPE)
                     o.conv_wgrad(self.cv_b[k - 1], slab[..., :k * F_], uk, GW(f"{pre}{k}.0"), db=GB(f"{pre}{k}.0"))
-                    o.conv_dgrad(self.cv_b[k - 1], uk, WD(f"{pre}{k}.0"), gs[..., :k * F_], accumulate=True)
+                    if k > 1:
+                        o.conv_dgrad(self.cv_b[k - 1], uk, WD(f"{pre}{k}.0"), gs[..., :k * F_], accumulate=True,
+                                     mask=slab[..., :k * F_], mask_slope=G_SLOPE, mask_c0=(k - 1) * F_, mask_last=True)
+                    else:
+                        o.conv_dgrad(self.cv_b[0], uk, WD(f"{pre}1.0"), gs[..., :F_], accumulate=True)
                 go = gs[..., :F_]                         # d x_drb = d o of the previous dense block
             gyn = bw["gy"][gyi ^ 1]
             o.axpby(gyn, go, 1.0, gy, 1.0)                # d x_rrdb = d x_drb(3i) + d y (identity path)

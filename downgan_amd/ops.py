@@ -112,7 +112,9 @@ class HipOps:
         epilogue operands (residuals, activation mask, accumulate) that are passed."""
         es = 2 if self.dtype == "bf16" else 4
         out = cv.N * cv.Ho * cv.Wo * cv.Cout
-        extra = 0 if ep is None else sum(1 for k in ("r1", "r2", "mask") if ep.get(k) is not None) + int(bool(ep.get("accumulate")))
+        extra = 0 if ep is None else sum(1 for k in ("r1", "r2") if ep.get(k) is not None) + int(bool(ep.get("accumulate")))
+        if ep is not None and ep.get("mask") is not None:      # only the channels from mask_c0 up are read
+            extra += 1.0 - float(ep.get("mask_c0", 0)) / cv.Cin if "mask_c0" in ep else 1
         return float(es * (cv.N * cv.H * cv.W * cv.Cin + out * (1 + extra) + 9 * cv.Cin * cv.Cout))
 
     def _act(self, t):
@@ -131,7 +133,7 @@ class HipOps:
         return (N, H, W, Cc // 64, 4)
 
     def _epilogue(self, out, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None, mask_slope=1.0,
-                  accumulate=False, mask_bits=None, out_bits=None):
+                  accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False):
         ep = Epilogue()
         ep.bias = bias.data_ptr() if bias is not None else None
         if bias is not None:
@@ -151,6 +153,9 @@ class HipOps:
             ep.mask = mask.data_ptr()
             ep.ldmask = pix_layout(mask)[0]
         ep.mask_slope = float(mask_slope)
+        assert mask_c0 % 16 == 0 and (mask is not None or (mask_c0 == 0 and not mask_last))
+        ep.mask_c0 = int(mask_c0)
+        ep.mask_last = int(bool(mask_last))
         ep.accumulate = int(accumulate)
         for name, t in (("mask_bits", mask_bits), ("out_bits", out_bits)):
             if t is not None:

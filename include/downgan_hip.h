@@ -44,7 +44,10 @@ typedef enum dg_status {
  *   if (r1) v = v*s1 + r1[pixel,c];  if (r2) v = v*s2 + r2[pixel,c];
  *   if (mask) v *= (mask[pixel,c] > 0 ? 1 : mask_slope);     -- LeakyReLU'(saved activation)
  *   if (accumulate) v += y[pixel,c];
- * r1/r2/mask are tensors of the OUTPUT's shape in `dtype`. */
+ * r1/r2/mask are tensors of the OUTPUT's shape in `dtype`.
+ * mask_c0 / mask_last (both 0 = the order above, every channel): the mask applies to channels c >= mask_c0 only
+ * (multiple of 16), and with mask_last != 0 it multiplies AFTER the accumulate -- the data gradient of a dense block's
+ * conv k completes channel slice k-1 of the block's gradient slab and applies that slice's LeakyReLU' in the same pass. */
 typedef struct dg_epilogue {
   const float* bias;
   int has_act;
@@ -59,6 +62,8 @@ typedef struct dg_epilogue {
    * launch as (stored value > 0).  Both need Cout % 64 == 0, Cout >= 128 and no pixel shuffle. */
   const void* mask_bits;
   void* out_bits;
+  int mask_c0;
+  int mask_last;
 } dg_epilogue;
 
 /* Geometry of ONE reference nn.Conv2d(Cin, Cout, kernel_size=3, stride, padding=1) layer

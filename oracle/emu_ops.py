@@ -75,7 +75,7 @@ class EmuOps:
         return torch.stack([(w[..., blk[c], g[c]] >> int(b[c])) & 1 for c in range(Cc)], dim=-1).bool()
 
     def _gather_gemm(self, d, x, w, y, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None,
-                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None):
+                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False):
         N = d.N
         xs = x.float()
         if d.src_ps:
@@ -117,14 +117,20 @@ class EmuOps:
             v = v * s1 + r1[sl].float()
         if r2 is not None:
             v = v * s2 + r2[sl].float()
-        if mask is not None:
-            v = v * _lgrad(mask[sl].float(), mask_slope)
+        def apply_mask(v):       # channels >= mask_c0 only (include/downgan_hip.h, dg_epilogue)
+            f = _lgrad(mask[sl].float(), mask_slope)
+            f = torch.where(torch.arange(v.shape[-1]) >= mask_c0, f, torch.ones(()))
+            return v * f
+        if mask is not None and not mask_last:
+            v = apply_mask(v)
         if mask_bits is not None:
             assert not d.dst_ps
             pos = self._unpack_bits(mask_bits[sl], y.shape[-1])
             v = v * torch.where(pos[..., :v.shape[-1]], torch.ones(()), torch.full((), float(mask_slope)))
         if accumulate:
             v = v + ysub.float()
+        if mask is not None and mask_last:
+            v = apply_mask(v)
         ysub.copy_(v.to(y.dtype))
         if out_bits is not None:
             assert not d.dst_ps and d.dy_mul == 1 and d.dx_mul == 1

@@ -97,7 +97,14 @@ def test_conv_dgrad(dtype, cfg):
     dy = rnd(emu.out_shape(cv), emu.tdtype, g)
     wd = rnd((co * 9 * ci,), emu.tdtype, g, 0.1)
     mask = rnd((N, H, W, ci), emu.tdtype, g)
-    for ep in (dict(), dict(mask=mask, mask_slope=0.2), dict(accumulate=True)):
+    # mask_c0 / mask_last: the mask for the upper channels only, applied after the accumulate (dense-block data gradients)
+    c_half = (ci // 2) // 16 * 16
+    eps = [dict(), dict(mask=mask, mask_slope=0.2), dict(accumulate=True),
+           dict(accumulate=True, mask=mask, mask_slope=0.2, mask_c0=c_half, mask_last=True),
+           dict(mask=mask, mask_slope=0.2, mask_c0=c_half)]
+    if ci >= 256:
+        eps.append(dict(accumulate=True, mask=mask, mask_slope=0.2, mask_c0=ci - 128, mask_last=True))
+    for ep in eps:
         dx_ref = rnd((N, H, W, ci), emu.tdtype, torch.Generator().manual_seed(6))
         dx = dx_ref.clone().cuda()
         emu.conv_dgrad(cv, dy, wd, dx_ref, **ep)
