@@ -52,3 +52,20 @@ def test_null_and_shape_errors_do_not_launch():
     assert lib.dg_conv3x3_wgrad(C.byref(g), None, None, None, None, None) == -3
     assert lib.dg_linear_fwd(_lib.DG_BF16, None, 0, None, 0, None, 0, 1, 16, 32, None) == -3
     assert lib.dg_adam(None, None, None, None, None, 16, 1e-3, 0.9, 0.99, 1e-8, 1, 1.0, None) == -3
+
+
+def test_integration_stub_matches_binding():
+    """The ctypes stub a reference maintainer would copy from INTEGRATION.md has the same field lists (= ABI layout) as the
+    package's own binding of dg_conv_geom / dg_epilogue."""
+    import ctypes as C
+    import os
+    from downgan_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = src[src.index("class ConvGeom(C.Structure)"):src.index("# critic.py:25-33")]
+    ns = {}
+    exec("import ctypes as C\n" + code, ns)
+    for name in ("ConvGeom", "Epilogue"):
+        mine, theirs = getattr(_lib, name), ns[name]
+        assert [f[0] for f in theirs._fields_] == [f[0] for f in mine._fields_], name
+        assert C.sizeof(theirs) == C.sizeof(mine), name
