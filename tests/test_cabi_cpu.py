@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 from downgan_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -69,3 +71,33 @@ def test_integration_stub_matches_binding():
         mine, theirs = getattr(_lib, name), ns[name]
         assert [f[0] for f in theirs._fields_] == [f[0] for f in mine._fields_], name
         assert C.sizeof(theirs) == C.sizeof(mine), name
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct of include/downgan_hip.h (compiled as plain C with gcc) equal the ctypes binding's:
+    a silent layout mismatch would hand the kernels garbage."""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    from downgan_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = [("dg_epilogue", _lib.Epilogue), ("dg_conv_geom", _lib.ConvGeom), ("dg_gg_desc", _lib.GGDesc),
+             ("dg_ssim_params", _lib.SsimParams), ("dg_msssim_combine", _lib.MsssimCombine)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{root}/include/downgan_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
