@@ -101,3 +101,18 @@ def test_struct_layouts_match_the_header(tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_product_path_fails_loudly_without_library_or_gpu(tmp_path):
+    """No CPU / eager fallback: a missing shared object raises on load, and the op layer refuses to start without a GPU."""
+    import subprocess
+    import sys
+    import torch
+    env = dict(os.environ, DG_LIB_OVERRIDE=str(tmp_path / "missing.so"))
+    r = subprocess.run([sys.executable, "-c", "from downgan_amd import _lib; _lib.lib()"], cwd=ROOT, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "RuntimeError" in r.stderr and "no CPU or eager fallback" in r.stderr, r.stderr[-400:]
+    if not torch.cuda.is_available():
+        from downgan_amd.ops import HipOps
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            HipOps("bf16")
