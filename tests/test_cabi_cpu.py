@@ -116,3 +116,32 @@ def test_product_path_fails_loudly_without_library_or_gpu(tmp_path):
         from downgan_amd.ops import HipOps
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             HipOps("bf16")
+
+
+def test_oracle_is_only_used_as_the_checker():
+    """oracle/ is test infrastructure: the package never imports it; bench.py only inside cpu_baseline(), __graft_entry__ only
+    inside smoke()."""
+    import ast
+    pkg = os.path.join(ROOT, "downgan_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, f)
+
+    def importing_functions(path):
+        tree = ast.parse(open(path).read())
+        out = set()
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            for n in ast.walk(fn):
+                if isinstance(n, (ast.Import, ast.ImportFrom)):
+                    names = [a.name for a in n.names] if isinstance(n, ast.Import) else [n.module or ""]
+                    if any(x == "oracle" or x.startswith("oracle.") for x in names):
+                        out.add(fn.name)
+        top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+        for n in top:
+            names = [a.name for a in n.names] if isinstance(n, ast.Import) else [n.module or ""]
+            assert not any(x == "oracle" or x.startswith("oracle.") for x in names), path
+        return out
+    assert importing_functions(os.path.join(ROOT, "bench.py")) <= {"cpu_baseline"}
+    assert importing_functions(os.path.join(ROOT, "__graft_entry__.py")) <= {"smoke"}
