@@ -879,17 +879,19 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
   static const bool no_im2col = getenv("DG_WG_NOIM2COL") != nullptr;
   if (!no_im2col && g->cin_real > 0 && g->cin_real <= 2 && g->stride == 1 && !g->pixel_shuffle && a.Wo % 32 == 0)
     return g->dtype == DG_F32 ? wg_launch_im2col<float>(a, st) : wg_launch_im2col<bf16_t>(a, st);
-  // measured per layer against the per-tap kernel: +4-10 % with >= 2 input-channel tiles or multi-megapixel batches,
-  // -20 % on the 128-channel 128^2 layers (too few workgroups per pixel range)
+  // narrow row-of-taps kernel (wg3) against the per-tap kernel: +4-10 % with >= 2 input-channel tiles or multi-megapixel
+  // batches, -20 % on the 128-channel 128^2 layers; the wide kernel (wg3w) takes every layer it is eligible for
   static const bool no_rows = getenv("DG_WG_NOROWS") != nullptr;
   static const bool no_wide = getenv("DG_WG_NOWIDE") != nullptr;
   static const bool no_wide_s2 = no_wide || getenv("DG_WG_NOWIDES2") != nullptr;
-  const bool rows = !no_rows && g->stride == 1 && a.Wo % 32 == 0 && a.Cout >= 64 && (a.Cin >= 256 || (a.Cin >= 64 && a.Mpix >= (1 << 22)));
   const bool wide = g->dtype == DG_BF16 && a.Cout >= 128 && a.Cin >= 128;
+  // (the -20 % of the row-of-taps shape on 128-channel 128^2 layers was the narrow wg3 kernel with the old split rounding: the
+  // wide kernel is +19-37 % there too)
+  const bool rows = !no_rows && g->stride == 1 && a.Wo % 32 == 0 && a.Cout >= 64 &&
+                    (a.Cin >= 256 || (a.Cin >= 64 && a.Mpix >= (1 << 22)) || (wide && !no_wide));
   const bool wide_s1 = rows && wide && !no_wide;
   // stride 2 on the wide kernel (x tile of 65 input pixels per 32 output pixels)
-  const bool wide_s2 = !no_rows && !no_wide_s2 && wide && g->stride == 2 && a.Wo % 32 == 0 && !g->pixel_shuffle &&
-                       (a.Cin >= 256 || a.Mpix >= (1 << 20));
+  const bool wide_s2 = !no_rows && !no_wide_s2 && wide && g->stride == 2 && a.Wo % 32 == 0 && !g->pixel_shuffle;
   static const bool no_fused_db = getenv("DG_WG_NOFUSEDDB") != nullptr;
   const bool fused_db = db && (wide_s1 || wide_s2) && !g->pixel_shuffle && !no_fused_db;   // the wide kernel sums the adjoint itself
   if (db && !fused_db) {   // bias gradient as a separate column-sum pass over the adjoint
