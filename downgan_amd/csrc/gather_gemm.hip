@@ -1653,9 +1653,23 @@ static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
   int tpb = tiles / 2048;            // a few tiles per workgroup so the weight tile is built rarely
   if (tpb < 1) tpb = 1;
   if (tpb > 16) tpb = 16;
+  // big launches: ONE round of the resident workgroups, every workgroup the same number of tiles (16 tiles per workgroup
+  // left 16384 workgroups on 768 slots: 21.3 rounds, the last a third full; +2 % at 1024^2)
+  const bool lean = !a.r1 && !a.r2 && !a.mask && !a.accumulate;
+  static int occ[2] = {0, 0};
+  if (!occ[lean]) {
+    int n = 0;
+    const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gg_im2col_kernel<T, true>, 256, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gg_im2col_kernel<T, false>, 256, 0);
+    occ[lean] = (e == hipSuccess && n > 0) ? n : 2;
+  }
+  const int slots = 256 * occ[lean];
+  if (tiles >= 8 * slots) tpb = (tiles + slots - 1) / slots;
+  static const int tpb_env = getenv("DG_GG_IM2COL_TPB") ? atoi(getenv("DG_GG_IM2COL_TPB")) : 0;
+  if (tpb_env > 0) tpb = tpb_env;
   dim3 grid((tiles + tpb - 1) / tpb, (a.Nout + 127) / 128);
   g_last_kinds |= 16;
-  if (!a.r1 && !a.r2 && !a.mask && !a.accumulate) hipLaunchKernelGGL((gg_im2col_kernel<T, true>), grid, dim3(256), 0, st, a, tpb);
+  if (lean) hipLaunchKernelGGL((gg_im2col_kernel<T, true>), grid, dim3(256), 0, st, a, tpb);
   else hipLaunchKernelGGL((gg_im2col_kernel<T, false>), grid, dim3(256), 0, st, a, tpb);
   return dg_check_launch();
 }
