@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — train-step samples/sec (G+D+GP) of the native WGAN-GP step on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 is launched by torch.distributed.run,
-one rank per GPU over RCCL).  A "step" is one minibatch through the critic iteration plus the
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N>1 either the driver starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, WORLD_SIZE set) or, typed bare, this
+script starts them itself (`self_launch`: N fresh child processes before any GPU call); one rank per GPU over RCCL.  A "step" is one minibatch through the critic iteration plus the
 generator iteration when step % 5 == 0 (reference DoWnGAN/GAN/wasserstein.py:131-147; the metrics
 pass :140 is excluded); the timed region always opens with a generator step, so K timed steps hold ceil(K/5)
 generator iterations whatever --steps / --warmup are.  Workload at N=1 = BASELINE.json configs[1]: batch 32 per GPU, 2-channel
@@ -37,7 +38,9 @@ WORKLOADS = {
 
 
 def conv_flops_per_sample(S, F_, cin_p, np_p, nrb, nup=3):
-    """Forward GFLOP/sample of generator (Gf) and critic (Cf) convs+linears, padded channels."""
+    """Forward flops/sample of generator (Gf) and critic (Cf) convs + linears.  Call it with the REAL channel
+    counts of the reference layers (2 / 6 inputs, 2 predictands, 100 FC rows) for the algorithmic figures every fraction is
+    quoted on (cfg2: Gf 4203.8, Cf 778.8 GFLOP), or with the padded ones for the flops the kernels actually execute."""
     gf = 2 * 9 * cin_p * F_ * S * S
     gf += nrb * 3 * sum(2 * 9 * k * F_ * F_ * S * S for k in range(1, 6))
     gf += 2 * 9 * F_ * F_ * S * S
@@ -71,53 +74,91 @@ def host_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, wl):
-    """The CPU oracle (a port: oracle/ref_step.py, PyTorch-CPU fp32) timed on this box's host cores on a
-    BOUNDED sample of the same workload.  The full 128->1024 tile costs ~25 TFLOP per sample-step, minutes
-    per sample on host cores (torch's CPU double-backward of conv runs at ~0.07 TFLOP/s), so the sample is
-    the workload's own networks (same filters / RRDB count) on a tile 2x smaller per side, batch 1: one
-    critic iteration + one generator iteration.  Every conv/linear flop scales with the tile area, so
-    samples/s at the full tile = sample rate / area ratio; this is stated in `sample`."""
+    """The CPU oracle (a port: oracle/ref_step.py, PyTorch-CPU fp32, all host cores) timed per SURVEY.md 8(d)(ii): the
+    workload's OWN tile and networks (cfg2: 2ch 128x128 -> 1024x1024, F=128, 16 RRDBs) at batch 1 -- one warm-up critic
+    iteration, then `critic_iterations` critic iterations + 1 generator iteration = the reference's 5-step cycle
+    (wasserstein.py:131-147).  samples/s = 5 samples-steps / that time; linear in the batch (B=32 on host cores would be
+    ~475 TFLOP per step), stated as such.  On a slow host the timed critic iterations are cut to fit ~2 minutes."""
     import torch
     from downgan_amd import synthetic
     from oracle import ref_step
     B, S, F_, cin, nrb = wl
-    shrink = 2 if S >= 64 else 1
-    Ss = S // shrink
     cores = host_cores()
     torch.set_num_threads(cores)
     pg = {k: torch.from_numpy(v) for k, v in synthetic.generator_params(F_, cin, 2, nrb).items()}
-    pc = {k: torch.from_numpy(v) for k, v in synthetic.critic_params(F_, 8 * Ss, 2).items()}
+    pc = {k: torch.from_numpy(v) for k, v in synthetic.critic_params(F_, 8 * S, 2).items()}
     tr = ref_step.OracleTrainer(pg, pc, ref_step.HP(batch_size=1), num_res_blocks=nrb)
-    coarse, fine = synthetic.tiles(1, cin, Ss)
+    coarse, fine = synthetic.tiles(1, cin, S)
     coarse, fine = torch.from_numpy(coarse), torch.from_numpy(fine)
-    alpha = torch.from_numpy(synthetic.alpha(1, 0))
     t0 = time.perf_counter()
-    tr.critic_iteration(coarse, fine, alpha)
-    tc = time.perf_counter() - t0
+    tr.critic_iteration(coarse, fine, torch.from_numpy(synthetic.alpha(1, 0)))            # warm-up (allocator, thread pool)
+    tw = time.perf_counter() - t0
+    ci = 5
+    n_crit = ci if tw < 30.0 else max(1, min(ci, int(100.0 / tw)))
+    t0 = time.perf_counter()
+    for i in range(n_crit):
+        tr.critic_iteration(coarse, fine, torch.from_numpy(synthetic.alpha(1, 1 + i)))
+    tc = (time.perf_counter() - t0) / n_crit
     t0 = time.perf_counter()
     tr.generator_iteration(coarse, fine)
     tg = time.perf_counter() - t0
-    area = shrink * shrink
-    sample = (f"oracle port, batch 1, {cin}ch {Ss}x{Ss}->{8 * Ss}x{8 * Ss} tile with the workload's networks (F={F_}, {nrb} RRDBs), "
-              f"fp32: 1 critic iteration {tc:.1f}s + 1 generator iteration {tg:.1f}s; step time = critic + generator/5; "
-              f"scaled by the tile-area ratio {area}x to the {S}->{8 * S} tile (all conv/linear flops scale with area)")
-    return {"value": 1.0 / ((tc + tg / 5.0) * area), "unit": "samples/s", "cores": cores, "kind": "port", "sample": sample}
+    sample = (f"oracle port (oracle/ref_step.py, PyTorch-CPU fp32), {cores} threads on '{cpu_model()}', the workload's own tile and networks "
+              f"at batch 1 ({cin}ch {S}x{S}->{8 * S}x{8 * S}, F={F_}, {nrb} RRDBs): warm-up critic iteration {tw:.1f}s, then "
+              f"{n_crit} critic iterations at {tc:.1f}s each + 1 generator iteration {tg:.1f}s; value = 1 / (critic + generator/5) samples/s "
+              f"(the reference's 5-step cycle; per-sample cost is independent of the batch, so B={B} is this rate, not {B}x it)")
+    return {"value": 1.0 / (tc + tg / ci), "unit": "samples/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port", "sample": sample}
+
+
+def lib_sha256():
+    import hashlib
+    from downgan_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
 
 
 def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction).  PMC counters cannot be
-    collected from inside the process, so the number is read from profiles/ and is null for any other workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_cfg2_bf16.json")
-    if args.workload != "cfg2" or args.dtype != "bf16" or args.batch or not os.path.exists(path):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command (tools/pmc_summary.py: separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction).  PMC counters cannot be collected from inside the process, so the
+    number comes from profiles/ -- and only when that file was produced with THIS build of the library (it records the
+    sha256 of libdowngan_hip.so): after any kernel change the entry is null until the passes are re-run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{args.workload}_{args.dtype}.json")
+    if args.batch or not os.path.exists(path):
         return None, None
     with open(path) as f:
         d = json.load(f)
+    if d.get("lib_sha256") != lib_sha256():
+        return None, f"profiles/{os.path.basename(path)} is from another build of libdowngan_hip.so (stale): traffic withheld"
     for k, v in d["kernels"].items():
         if k.startswith(kernel):
-            return round(v["traffic_bytes_per_launch"]), "profiles/pmc_traffic_cfg2_bf16.json (" + d["formula"] + ")"
+            return round(v["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(path)} (" + d["formula"] + ")"
     return None, None
+
+
+def self_launch(n):
+    """Start `n` rank processes of this script (one per GPU, RCCL rendezvous on 127.0.0.1) and return their exit code.
+    Runs BEFORE anything initialises the GPU in this process; the children are new processes, nothing is re-exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def main():
@@ -135,6 +176,11 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gradient exchange goes over gloo")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this parent process never imports torch and never touches the GPU; it starts N
+        # FRESH rank processes (one per GPU) through torch.distributed.run and relays their output -- rank 0 prints the JSON line.
+        sys.exit(self_launch(args.gpus))
 
     import torch
     from downgan_amd import synthetic
@@ -229,18 +275,29 @@ def main():
                     "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "alg_bytes_per_launch": round(alg_bytes),
                     "launches": nl, "avg_launch_ms": round(sec / max(nl, 1) * 1e3, 4),
                     "share_of_step": round(sec / elapsed, 3)}
-        # critic conv stack (BASELINE target: >= 40 % MFMA utilisation): every conv launch of the critic (forward, data- and
-        # weight-gradient of its 8 conv layers, incl. the HBM-bound 2-channel first layer), algorithmic flops / summed durations
-        cf = sum(v[0] for t, v in agg.items() if t.startswith("conv") and ":C" in t)
-        cs = sum(v[1] for t, v in agg.items() if t.startswith("conv") and ":C" in t)
+        # critic stack (BASELINE target: >= 40 % MFMA utilisation; SURVEY 8(d): 10.4*Cf*B / t_critic_kernels): EVERY kernel of
+        # the critic -- conv forward / data / weight gradients of its 8 layers incl. the HBM-bound 2-channel first layer, the
+        # Linear kernels (lin_*), bias/activation and the penalty's elementwise passes (ew_*) -- algorithmic flops (real
+        # channels) / summed launch durations.  `conv_only` is the same without the lin_* / ew_* launches.
+        isc = lambda t: ":C" in t
+        cf = sum(v[0] for t, v in agg.items() if isc(t))
+        cs = sum(v[1] for t, v in agg.items() if isc(t))
+        ccf = sum(v[0] for t, v in agg.items() if isc(t) and t.startswith("conv"))
+        ccs = sum(v[1] for t, v in agg.items() if isc(t) and t.startswith("conv"))
         critic_stack = {"tflops": round(cf / cs / 1e12, 2) if cs > 0 else None, "mfma_frac": round(cf / cs / 1e12 / peak, 4) if cs > 0 else None,
-                        "share_of_step": round(cs / elapsed, 3)}
+                        "share_of_step": round(cs / elapsed, 3),
+                        "conv_only": {"tflops": round(ccf / ccs / 1e12, 2) if ccs > 0 else None,
+                                      "mfma_frac": round(ccf / ccs / 1e12 / peak, 4) if ccs > 0 else None},
+                        "alg_tflop_per_step": round(cf / args.steps / 1e12, 3)}
         ops.prof = None
 
     if rank == 0:
-        gf, cf = conv_flops_per_sample(S, F_, eng.G.cin_p, eng.G.np_p, nrb)
+        gf, cf = conv_flops_per_sample(S, F_, cin, 2, nrb)                          # real channels: algorithmic
+        gfp, cfp = conv_flops_per_sample(S, F_, eng.G.cin_p, eng.G.np_p, nrb)       # zero-padded channels: what the MFMAs execute
         value = args.steps * B * world / elapsed
-        w_step = (1.6 * gf + 10.4 * cf)
+        w_survey = 1.6 * gf + 10.4 * cf        # SURVEY 8(d) necessary work: critic iteration Gf + 10 Cf, generator iteration 3 Gf + 2 Cf
+        w_step = 1.4 * gf + 10.4 * cf          # executed: on generator steps ONE G(coarse) serves both iterations (engine.train_step)
+        w_padded = 1.4 * gfp + 10.4 * cfp
         out = {
             "metric": "train-step samples/sec (G+D+GP)", "value": round(value, 4), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -248,7 +305,12 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: batch {B}/GPU (global {B * world}), {cin}ch {S}x{S}->{8 * S}x{8 * S}, "
                                    f"filters {F_}, {nrb} RRDBs, WGAN-GP critic step every step + generator step every 5th",
-                       "parallelism": f"dp{world}", "alg_tflop_per_sample_step": round(w_step / 1e12, 4),
+                       "parallelism": f"dp{world}", "per_gpu_batch": B, "global_batch": B * world,
+                       "alg_tflop_per_sample_step": round(w_step / 1e12, 4),
+                       "alg_tflop_per_sample_step_survey": round(w_survey / 1e12, 4),
+                       "executed_padded_tflop_per_sample_step": round(w_padded / 1e12, 4),
+                       "work": "1.4*Gf + 10.4*Cf per sample-step, real channels (SURVEY 8(d) counts 1.6*Gf: the generator iteration's "
+                               "G(coarse) is the critic iteration's, computed once)",
                        "generator_steps_in_timed_region": gen_steps_timed},
             "step_mfma_frac": round(w_step * value / world / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4),
             "losses": {k: scal[k] for k in ("critic_loss", "gp_ret", "g_loss") if k in scal},

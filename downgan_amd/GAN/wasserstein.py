@@ -54,17 +54,19 @@ class WassersteinGAN:
             return torch.rand(e.B, device=e.ops.device, dtype=torch.float32)     # wasserstein.py:91
         return torch.as_tensor(alpha, dtype=torch.float32).reshape(-1).to(e.ops.device)
 
-    def _critic_train_iteration(self, coarse, fine, alpha=None):
+    def _critic_train_iteration(self, coarse, fine, alpha=None, _keep_g=False):
+        """``_keep_g`` (set by ``_train_epoch`` on generator steps): keep G(coarse) of this iteration for the generator
+        iteration that follows on the same batch, which then skips its own identical forward."""
         e = self._eng(coarse, fine)
         xc, xf = self._to_native(e, coarse, fine)
-        e.critic_iteration(xc, xf, self._alpha(e, alpha))
+        e.critic_iteration(xc, xf, self._alpha(e, alpha), save_g=_keep_g)
         self.last = e.read_scalars(False)
         return self.last
 
-    def _generator_train_iteration(self, coarse, fine):
+    def _generator_train_iteration(self, coarse, fine, _reuse_g=False):
         e = self._eng(coarse, fine)
         xc, xf = self._to_native(e, coarse, fine)
-        e.generator_iteration(xc, xf)
+        e.generator_iteration(xc, xf, reuse_fake=_reuse_g)
         out = e.read_scalars(True)
         self.last.update({k: out[k] for k in ("g_loss", "content_loss", "g_c_fake_mean")})
         return {k: out[k] for k in ("g_loss", "content_loss", "g_c_fake_mean")}
@@ -97,9 +99,10 @@ class WassersteinGAN:
         log = []
         for data in dataloader:
             coarse, fine = data[0], data[1]
-            out = dict(self._critic_train_iteration(coarse, fine))
-            if self.num_steps % hp.critic_iterations == 0:                        # :136
-                out.update(self._generator_train_iteration(coarse, fine))
+            gen_step = self.num_steps % hp.critic_iterations == 0                 # :136
+            out = dict(self._critic_train_iteration(coarse, fine, _keep_g=gen_step))
+            if gen_step:
+                out.update(self._generator_train_iteration(coarse, fine, _reuse_g=True))
             self.num_steps += 1
             if self._engine is not None:
                 self._engine.num_steps = self.num_steps

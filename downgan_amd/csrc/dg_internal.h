@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/downgan_hip.h"
 
 typedef unsigned short bf16_t;  // raw bf16 bits
@@ -61,6 +63,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int dg_check_launch() { return hipGetLastError() == hipSuccess ? DG_OK : DG_ERR_LAUNCH; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: a launcher that set it once per process would launch
+// > 64 KB of dynamic LDS without it on a second device of the same process.  Bit d of `done` = "device d is configured";
+// two threads racing through the first call both run the (idempotent) setter.  The only mutable state of the library are
+// these per-kernel device masks and the cached occupancy answers (std::atomic, same value on every MI355X).
+static inline int dg_set_max_lds_once(std::atomic<unsigned long long>& done, const void* kernel, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return DG_ERR_LAUNCH;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return DG_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return DG_ERR_LAUNCH;
+  done.fetch_or(bit, std::memory_order_release);
+  return DG_OK;
+}
+#define DG_SET_MAX_LDS_ONCE(kernel, bytes)                                                                        \
+  do {                                                                                                            \
+    static std::atomic<unsigned long long> dg_done_{0};                                                           \
+    if (dg_set_max_lds_once(dg_done_, reinterpret_cast<const void*>(kernel), (bytes)) != DG_OK) return DG_ERR_LAUNCH; \
+  } while (0)
 
 // bijective XCD-aware remap of a linear block id: blocks that share an XCD (id % 8 equal) get a
 // contiguous range of logical tiles, so neighbouring tiles share that XCD's L2 (speed only).

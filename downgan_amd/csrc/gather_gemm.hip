@@ -1036,12 +1036,7 @@ __global__ __launch_bounds__(512) void gg_halo128_kernel(const GGArgs a, int til
 template <typename T, int MODE>
 static int gg_launch_halo128(GGArgs& a, int N, hipStream_t st) {
   constexpr int LDS_BYTES = 324 * 272 + 2 * 128 * 256;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo128_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return DG_ERR_LAUNCH;
-    attr_set = true;
-  }
+  DG_SET_MAX_LDS_ONCE((&gg_halo128_kernel<T, MODE>), LDS_BYTES);
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
   a.nct = (unsigned)((a.Nout + 127) / 128);
   a.nwg = (MODE == 2 ? 1u : a.nct) * (unsigned)(tiles_x * tiles_y * N);
@@ -1307,12 +1302,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
 template <typename T, bool S2, bool PS = false>
 static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
   constexpr int LDS_BYTES = 324 * 144 + 2 * 128 * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo4w_kernel<T, S2, PS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return DG_ERR_LAUNCH;
-    attr_set = true;
-  }
+  DG_SET_MAX_LDS_ONCE((&gg_halo4w_kernel<T, S2, PS>), LDS_BYTES);
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
   a.nct = (unsigned)((a.Nout + 127) / 128);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
@@ -1475,12 +1465,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo16_kernel(const GGArgs a, int t
 template <typename T>
 static int gg_launch_halo16(GGArgs& a, int N, hipStream_t st) {
   constexpr int LDS_BYTES = (324 + 9 * 16) * 144;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_halo16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return DG_ERR_LAUNCH;
-    attr_set = true;
-  }
+  DG_SET_MAX_LDS_ONCE((&gg_halo16_kernel<T>), LDS_BYTES);
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
   a.nct = 1;
   a.nwg = (unsigned)(tiles_x * tiles_y * N);
@@ -1656,14 +1641,16 @@ static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
   // big launches: ONE round of the resident workgroups, every workgroup the same number of tiles (16 tiles per workgroup
   // left 16384 workgroups on 768 slots: 21.3 rounds, the last a third full; +2 % at 1024^2)
   const bool lean = !a.r1 && !a.r2 && !a.mask && !a.accumulate;
-  static int occ[2] = {0, 0};
-  if (!occ[lean]) {
+  static std::atomic<int> occ_cache[2] = {{0}, {0}};
+  int occ = occ_cache[lean].load(std::memory_order_relaxed);
+  if (!occ) {
     int n = 0;
     const hipError_t e = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gg_im2col_kernel<T, true>, 256, 0)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gg_im2col_kernel<T, false>, 256, 0);
-    occ[lean] = (e == hipSuccess && n > 0) ? n : 2;
+    occ = (e == hipSuccess && n > 0) ? n : 2;
+    occ_cache[lean].store(occ, std::memory_order_relaxed);
   }
-  const int slots = 256 * occ[lean];
+  const int slots = 256 * occ;
   if (tiles >= 8 * slots) tpb = (tiles + slots - 1) / slots;
   static const int tpb_env = getenv("DG_GG_IM2COL_TPB") ? atoi(getenv("DG_GG_IM2COL_TPB")) : 0;
   if (tpb_env > 0) tpb = tpb_env;

@@ -341,10 +341,14 @@ static int wg_launch_im2col(WGArgs& a, hipStream_t st) {
   const int nco_t = (a.Cout + bco - 1) / bco;
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
   const int lds = 2 * 32 * (bco + 64 + 2 * PADE) * (int)sizeof(T);
-  static int occ[2] = {0, 0};
-  if (!occ[big_co]) occ[big_co] = big_co ? wg_resident(wg_kernel<T, 128, 64, true, 32, true>, lds) : wg_resident(wg_kernel<T, 64, 64, true, 32, true>, lds);
+  static std::atomic<int> occ_cache[2] = {{0}, {0}};
+  int occ = occ_cache[big_co].load(std::memory_order_relaxed);
+  if (!occ) {
+    occ = big_co ? wg_resident(wg_kernel<T, 128, 64, true, 32, true>, lds) : wg_resident(wg_kernel<T, 64, 64, true, 32, true>, lds);
+    occ_cache[big_co].store(occ, std::memory_order_relaxed);
+  }
   // two whole rounds of the resident slots (2304 workgroups on 5 x 256 slots were 1.8 rounds)
-  int splits = 2 * 256 * occ[big_co] / nco_t;
+  int splits = 2 * 256 * occ / nco_t;
   const int max_splits = (a.Mpix + 2047) / 2048;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -379,14 +383,10 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
 #define WG_LAUNCH1(BCO, BCI, RS, KPV)                                                                 \
   do {                                                                                                \
     const int lds = 2 * KPV * (BCO + BCI + 2 * PADE) * (int)sizeof(T);                                \
-    static bool attr = false;                                                                         \
-    if (!attr && lds > 65536) {                                                                       \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wg_kernel<T, BCO, BCI, RS, KPV>),        \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DG_ERR_LAUNCH; \
-      attr = true;                                                                                    \
-    }                                                                                                 \
-    static int occ = 0;                                                                               \
-    if (!occ) occ = wg_resident(wg_kernel<T, BCO, BCI, RS, KPV>, lds);                                \
+    if (lds > 65536) DG_SET_MAX_LDS_ONCE((&wg_kernel<T, BCO, BCI, RS, KPV>), lds);                    \
+    static std::atomic<int> occ_cache{0};                                                             \
+    int occ = occ_cache.load(std::memory_order_relaxed);                                              \
+    if (!occ) { occ = wg_resident(wg_kernel<T, BCO, BCI, RS, KPV>, lds); occ_cache.store(occ, std::memory_order_relaxed); } \
     /* 3 rounds of the resident slots, 2 when more than 3 workgroups share a CU */                    \
     const long long target = target_blocks ? target_blocks : (long long)(occ > 3 ? 2 : 3) * 256 * occ; \
     const int splits = wg_pick_splits(ntiles, target, cap, a.Mpix, &a.ppb);                           \
@@ -612,12 +612,7 @@ static int wg3_launch(WGArgs& a, hipStream_t st) {
   const int splits = wg_pick_splits(ntiles, 2304, cap, a.Mpix, &a.ppb);             // 3 rounds of 768 slots (3 per CU)
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
   const int lds = 2 * (32 * (BCO + PADE) + 34 * (BCI + PADE)) * (int)sizeof(T);
-  static bool attr = false;
-  if (!attr && lds > 65536) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wg3_kernel<T, BCO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return DG_ERR_LAUNCH;
-    attr = true;
-  }
+  if (lds > 65536) DG_SET_MAX_LDS_ONCE((&wg3_kernel<T, BCO>), lds);
   hipLaunchKernelGGL((wg3_kernel<T, BCO>), dim3(ntiles, splits), dim3(256), lds, st, a);
   return dg_check_launch();
 }
@@ -844,12 +839,7 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
   static const int tb_env = getenv("DG_WG_TB") ? atoi(getenv("DG_WG_TB")) : 1536;
   const int splits = wg_pick_splits(ntiles, tb_env, cap, a.Mpix, &a.ppb);           // 3 rounds of 512 slots (2 per CU)
   constexpr int lds = 3 * (32 * 256 + (S2 ? 68 : 36) * 256);
-  static bool attr = false;
-  if (!attr && lds > 65536) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wg3w_kernel<S2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return DG_ERR_LAUNCH;
-    attr = true;
-  }
+  if (lds > 65536) DG_SET_MAX_LDS_ONCE((&wg3w_kernel<S2>), lds);
   hipLaunchKernelGGL((wg3w_kernel<S2>), dim3(ntiles, splits), dim3(256), lds, st, a);
   return dg_check_launch();
 }

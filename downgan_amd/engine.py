@@ -170,7 +170,8 @@ class NativeCritic:
         h = fine_dim
         for l, st in enumerate(self.STRIDES):
             self.convs.append(Conv(batch, h, h, self.c_pad[l], self.c_pad[l + 1], st, False,
-                                   cin_real=(nc if l == 0 and nc <= 2 else 0), net="C"))
+                                   cin_real=(nc if l == 0 and nc <= 2 else 0), net="C",
+                                   cin_alg=self.c_real[l], cout_alg=self.c_real[l + 1]))
             h //= st
         self.hf = h
         self.fc_k = h * h * self.c_pad[8]
@@ -248,10 +249,10 @@ class NativeCritic:
             cur = self.acts[l]
         y7 = self.acts[7].view(self.B, self.fc_k)
         self.h1pre.zero_()
-        o.linear_fwd(y7, P.w2d("classifier.0.weight"), self.h1pre)
+        o.linear_fwd(y7, P.w2d("classifier.0.weight"), self.h1pre, o_real=FC_HID, net="C")
         o.bias_act(self.h1pre, P.master("classifier.0.bias"), self.h1, act=C_SLOPE)
         self.outpre.zero_()
-        o.linear_fwd(self.h1, P.w2d("classifier.2.weight"), self.outpre)
+        o.linear_fwd(self.h1, P.w2d("classifier.2.weight"), self.outpre, o_real=1, net="C")
         o.bias_act(self.outpre, P.master("classifier.2.bias"), self.out)
         return self.out
 
@@ -265,14 +266,14 @@ class NativeCritic:
         o.fill_col(self.dout, 0, dout_value)
         y7 = self.acts[7].view(self.B, self.fc_k)
         if wgrad:
-            o.linear_dw(self.dout, self.h1, P.grad("classifier.2.weight"))
+            o.linear_dw(self.dout, self.h1, P.grad("classifier.2.weight"), o_real=1, net="C")
             o.colsum(self.dout, P.grad("classifier.2.bias"))
-        o.linear_dx(self.dout, P.w2d("classifier.2.weight"), self.uh1, mask=self.h1, mask_slope=C_SLOPE)
+        o.linear_dx(self.dout, P.w2d("classifier.2.weight"), self.uh1, mask=self.h1, mask_slope=C_SLOPE, o_real=1, net="C")
         if wgrad:
-            o.linear_dw(self.uh1[:, :FC_HID_P], y7, P.grad("classifier.0.weight"))
+            o.linear_dw(self.uh1[:, :FC_HID_P], y7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
             o.colsum(self.uh1, P.grad("classifier.0.bias"))
         o.linear_dx(self.uh1[:, :FC_HID_P], P.w2d("classifier.0.weight"), self.us[7].view(self.B, self.fc_k),
-                    mask=y7, mask_slope=C_SLOPE)
+                    mask=y7, mask_slope=C_SLOPE, o_real=FC_HID, net="C")
         for l in range(7, -1, -1):
             cv = self.convs[l]
             name = f"features.{2 * l}.weight"
@@ -319,11 +320,11 @@ class NativeCritic:
                 o.conv_fwd(cv, t, P.w(name), tn, mask=self.acts[l], mask_slope=C_SLOPE)
             t = tn
         t7 = t.view(self.B, self.fc_k)
-        o.linear_dw(self.uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"))
+        o.linear_dw(self.uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
         self._th1pre.zero_()
-        o.linear_fwd(t7, P.w2d("classifier.0.weight"), self._th1pre)
+        o.linear_fwd(t7, P.w2d("classifier.0.weight"), self._th1pre, o_real=FC_HID, net="C")
         o.bias_act(self._th1pre, None, self._th1, mask=self.h1, mask_slope=C_SLOPE)
-        o.linear_dw(self._ones, self._th1, P.grad("classifier.2.weight"))
+        o.linear_dw(self._ones, self._th1, P.grad("classifier.2.weight"), o_real=1, net="C")
 
 
 # =============================================================================================== generator
@@ -338,13 +339,13 @@ class NativeGenerator:
         self.cin_p, self.np_p = layout.pad16(channels), layout.pad16(n_predictands)
         self.nrb, self.nup = num_res_blocks, num_upsample
         F_, S, B = filters, coarse_side, batch
-        self.cv_conv1 = Conv(B, S, S, self.cin_p, F_, cin_real=(channels if channels <= 2 else 0))
+        self.cv_conv1 = Conv(B, S, S, self.cin_p, F_, cin_real=(channels if channels <= 2 else 0), cin_alg=channels)
         self.cv_b = [Conv(B, S, S, k * F_, F_) for k in range(1, 6)]
         self.cv_conv2 = Conv(B, S, S, F_, F_)
         self.cv_up = [Conv(B, S << u, S << u, F_, 4 * F_, 1, True) for u in range(num_upsample)]
         hs = S << num_upsample
         self.cv_c30 = Conv(B, hs, hs, F_, F_)
-        self.cv_c32 = Conv(B, hs, hs, F_, self.np_p)
+        self.cv_c32 = Conv(B, hs, hs, F_, self.np_p, cout_alg=n_predictands)
         P = self.P = ParamStore(ops)
 
         def addconv(name, cv, dgrad=True):
@@ -580,17 +581,27 @@ class TrainEngine:
         else:
             P.adam_step(self.hp, 1.0)
 
-    def critic_iteration(self, coarse, fine, alpha, apply_update=True):
+    def critic_iteration(self, coarse, fine, alpha, apply_update=True, save_g=False):
         """wasserstein.py:27-55.  coarse/fine: native NHWC tensors; alpha: fp32 [B] on the device
         (replaces torch.rand at :91).  The generator runs forward-only: its backward in the reference's
-        critic step is dead work (G grads are zeroed at :65 before any use)."""
+        critic step is dead work (G grads are zeroed at :65 before any use).
+
+        ``save_g``: keep the generator's dense-block slabs of this forward, so that a generator iteration that follows on
+        the SAME batch with the SAME generator parameters (wasserstein.py:134-137: every ``critic_iterations``-th step) can
+        skip its own, bit-identical ``G(coarse)`` (``generator_iteration(reuse_fake=True)``).
+        While the generator's own update is still in flight (data parallel: its gradient all-reduce, enqueued at the end of
+        the previous generator iteration), the real-sample pass -- which needs no generator -- runs first and hides it."""
         o, hp, C, B = self.ops, self.hp, self.C, self.B
         bg = B * self.world
-        fake = self.G.forward(coarse, save=False)                 # :35
+        real_first = self.G.P._pending is not None
+        if not real_first:
+            fake = self.G.forward(coarse, save=save_g)            # :35
         C.P.zero_grad()                                           # :43
         out = C.forward(fine)                                     # :37
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
         C.backward(fine, -1.0 / bg)                               # d(-mean c_real)
+        if real_first:
+            fake = self.G.forward(coarse, save=save_g)            # :35 (first use of G's parameters completes their update)
         out = C.forward(fake)                                     # :38
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
         C.backward(fake, 1.0 / bg)                                # d(+mean c_fake)
@@ -599,14 +610,16 @@ class TrainEngine:
         if apply_update:
             self._allreduce_and_step(C.P, defer=True)             # :52-55 (overlaps with the next generator forward)
 
-    def generator_iteration(self, coarse, fine, apply_update=True):
-        """wasserstein.py:58-83: g_loss = -mean(C(G(x)))*gamma + content_lambda*L1(G(x), y)."""
+    def generator_iteration(self, coarse, fine, apply_update=True, reuse_fake=False):
+        """wasserstein.py:58-83: g_loss = -mean(C(G(x)))*gamma + content_lambda*L1(G(x), y).
+        ``reuse_fake``: the preceding ``critic_iteration(save_g=True)`` already ran G(coarse) on this batch with these
+        parameters (only the critic was updated in between): its output and saved slabs are used as they are."""
         o, hp, C, G, B = self.ops, self.hp, self.C, self.G, self.B
         bg = B * self.world
         if self.dfake is None:
             self.dfake = o.zeros(*self.G.fake.shape)
         G.P.zero_grad()                                           # :65
-        fake = G.forward(coarse, save=True)                       # :67
+        fake = G.fake if reuse_fake else G.forward(coarse, save=True)   # :67
         out = C.forward(fake)                                     # :68
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("g_c_fake_mean"))
         C.backward(fake, -hp.gamma / bg, wgrad=False, dx=self.gbuf)            # d(-gamma*mean c_fake)/d fake
@@ -615,7 +628,7 @@ class TrainEngine:
              addend=self.gbuf)                                    # :78 + losses.py:51-53
         G.backward(coarse, self.dfake)                            # :80
         if apply_update:
-            self._allreduce_and_step(G.P)                         # :83
+            self._allreduce_and_step(G.P, defer=True)             # :83 (overlaps with the next critic iteration's real pass)
 
     def metrics_pass(self, coarse, fine):
         """Per-batch evaluation metrics of the reference's training loop (mlflow_tools/mlflow_epoch.py:53-63 called at
@@ -660,15 +673,17 @@ class TrainEngine:
         side = torch.cuda.Stream(device=o.device)
         side.wait_stream(torch.cuda.current_stream(o.device))
         with torch.cuda.stream(side):                       # eager warm-up: lazy workspaces, function attributes
-            self.critic_iteration(self._g_coarse, self._g_fine, self.alpha_dev, apply_update=False)
-            self.generator_iteration(self._g_coarse, self._g_fine, apply_update=False)
+            self.critic_iteration(self._g_coarse, self._g_fine, self.alpha_dev, apply_update=False, save_g=True)
+            self.generator_iteration(self._g_coarse, self._g_fine, apply_update=False, reuse_fake=True)
         torch.cuda.current_stream(o.device).wait_stream(side)
         torch.cuda.synchronize(o.device)
-        self._graph_c, self._graph_g = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self._graph_c, self._graph_cs, self._graph_g = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph_c):
             self.critic_iteration(self._g_coarse, self._g_fine, self.alpha_dev, apply_update=False)
-        with torch.cuda.graph(self._graph_g):
-            self.generator_iteration(self._g_coarse, self._g_fine, apply_update=False)
+        with torch.cuda.graph(self._graph_cs):                 # generator steps: the critic iteration keeps G's slabs ...
+            self.critic_iteration(self._g_coarse, self._g_fine, self.alpha_dev, apply_update=False, save_g=True)
+        with torch.cuda.graph(self._graph_g):                  # ... and the generator iteration starts from them
+            self.generator_iteration(self._g_coarse, self._g_fine, apply_update=False, reuse_fake=True)
         self.C.P.zero_grad(); self.G.P.zero_grad()
         self.graphs = True
 
@@ -683,15 +698,16 @@ class TrainEngine:
             if fine is not self._g_fine:
                 self._g_fine.copy_(fine)
             self.alpha_dev.copy_(alpha)
-            self._graph_c.replay()
+            (self._graph_cs if ran_g else self._graph_c).replay()
             self._allreduce_and_step(self.C.P)
             if ran_g:
                 self._graph_g.replay()
                 self._allreduce_and_step(self.G.P)
         else:
-            self.critic_iteration(coarse, fine, alpha)
+            # generator steps: ONE G(coarse) serves both iterations (same batch, same generator parameters)
+            self.critic_iteration(coarse, fine, alpha, save_g=ran_g)
             if ran_g:
-                self.generator_iteration(coarse, fine)
+                self.generator_iteration(coarse, fine, reuse_fake=True)
         self.num_steps += 1
         return ran_g
 
@@ -725,11 +741,11 @@ class TrainEngineFS(TrainEngine):
         self.real_high, self.fake_high = o.zeros(*shape), o.zeros(*shape)
         self.real_low = self.fake_low = self.tbuf = None
 
-    def critic_iteration(self, coarse, fine, alpha, apply_update=True):
+    def critic_iteration(self, coarse, fine, alpha, apply_update=True, save_g=False):
         """wasserstein_fs.py:28-60."""
         o, hp, C, B = self.ops, self.hp, self.C, self.B
         bg = B * self.world
-        fake = self.G.forward(coarse, save=False)                 # :36
+        fake = self.G.forward(coarse, save=save_g)                # :36
         o.lowpass5(fake, high=self.fake_high)                     # :37,40
         o.lowpass5(fine, high=self.real_high)                     # :38,41
         C.P.zero_grad()                                           # :49
@@ -744,7 +760,7 @@ class TrainEngineFS(TrainEngine):
         if apply_update:
             self._allreduce_and_step(C.P, defer=True)             # :57-60
 
-    def generator_iteration(self, coarse, fine, apply_update=True):
+    def generator_iteration(self, coarse, fine, apply_update=True, reuse_fake=False):
         """wasserstein_fs.py:63-92: g_loss = -gamma*mean C(fake_high) + content_lambda*L1(fake_low, real_low); the gradient
         reaches ``fake`` through both branches: d fake = d_high + low^T(g_L1 - d_high)."""
         o, hp, C, G, B = self.ops, self.hp, self.C, self.G, self.B
@@ -754,7 +770,7 @@ class TrainEngineFS(TrainEngine):
         if self.tbuf is None:
             self.real_low, self.fake_low, self.tbuf = (o.zeros(*self.xhat.shape) for _ in range(3))
         G.P.zero_grad()                                           # :70
-        fake = G.forward(coarse, save=True)                       # :72
+        fake = G.fake if reuse_fake else G.forward(coarse, save=True)   # :72
         o.lowpass5(fake, low=self.fake_low, high=self.fake_high)  # :73,76
         o.lowpass5(fine, low=self.real_low)                       # :74
         out = C.forward(self.fake_high)                           # :79
@@ -768,4 +784,4 @@ class TrainEngineFS(TrainEngine):
         o.axpby(self.dfake, self.dfake, 1.0, self.gbuf, 1.0)       # + d_high
         G.backward(coarse, self.dfake)                            # :88
         if apply_update:
-            self._allreduce_and_step(G.P)                         # :91
+            self._allreduce_and_step(G.P, defer=True)             # :91

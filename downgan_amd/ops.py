@@ -35,6 +35,8 @@ class Conv:
     pixel_shuffle: bool = False
     cin_real: int = 0   # real (unpadded) input channels when that is <= 2, else 0
     net: str = ""       # "C" for critic layers: bench.py reports the critic conv stack's MFMA utilisation separately
+    cin_alg: int = 0    # real channel counts of the reference layer (0 = same as padded): ALGORITHMIC flops / bytes only,
+    cout_alg: int = 0   # zero padding is not counted as work
 
     @property
     def Ho(self):
@@ -72,11 +74,15 @@ class HipOps:
         self.tdtype = TORCH_DTYPE[dtype]
         self.dg = DG_DTYPE[dtype]
         self.device = torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.lib = _lib.lib()
         self.prof = None      # optional list of (tag, flops, bytes, start_event, end_event): bench.py's live kernel timing
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
+        # the C ABI launches on the CURRENT HIP device (function attributes are per device): keep it equal to this backend's
+        if torch.cuda.current_device() != self._dev_index:
+            torch.cuda.set_device(self.device)
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     per_layer = False     # bench.py --per-layer: tag conv launches with their layer geometry
@@ -104,8 +110,9 @@ class HipOps:
 
     @staticmethod
     def conv_flops(cv):
-        """algorithmic flops of one conv pass: 2*9*Cin*Cout*Ho*Wo per image, padded channels."""
-        return 2.0 * 9 * cv.Cin * cv.Cout * cv.Ho * cv.Wo * cv.N
+        """algorithmic flops of one conv pass: 2*9*Cin*Cout*Ho*Wo per image with the REFERENCE layer's
+        channel counts -- the zero-padded channels the kernels also multiply are not work."""
+        return 2.0 * 9 * (cv.cin_alg or cv.Cin) * (cv.cout_alg or cv.Cout) * cv.Ho * cv.Wo * cv.N
 
     def conv_bytes(self, cv, ep=None):
         """algorithmic HBM bytes of one conv pass: input + output + weights once each, plus the output-sized
@@ -231,16 +238,18 @@ class HipOps:
         check(self.lib.dg_repack_conv_weights(self.dg, kind, _ptr(master), _ptr(dst), cout, cin, self._stream()), "dg_repack_conv_weights")
 
     # ------------------------------------------------------------------ linear family
-    def linear_fwd(self, x, w, y):
+    def linear_fwd(self, x, w, y, o_real=0, net=""):
         """y[B,ldy] (fp32, pre-zeroed) += x[B,K] @ w[O,K]^T"""
         self._act(x); self._act(w)
         B, K = x.shape
         O = w.shape[0]
         assert w.shape[1] == K and y.dtype == torch.float32 and y.shape[0] == B and y.shape[1] >= O
-        check(self.lib.dg_linear_fwd(self.dg, _ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(y), y.stride(0), B, O, K,
-                                     self._stream()), "dg_linear_fwd")
+        es = x.element_size()
+        check(self._timed("lin_fwd", 2.0 * B * (o_real or O) * K, lambda: self.lib.dg_linear_fwd(
+            self.dg, _ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(y), y.stride(0), B, O, K, self._stream()),
+            float(es * (B * K + O * K)), net), "dg_linear_fwd")
 
-    def linear_dx(self, dy, w, dx, mask=None, mask_slope=1.0):
+    def linear_dx(self, dy, w, dx, mask=None, mask_slope=1.0, o_real=0, net=""):
         """dx[B,K] = (dy[B,O] @ w[O,K]) * leaky'(mask)"""
         self._act(w)
         B, K = dx.shape
@@ -250,18 +259,21 @@ class HipOps:
         if mask is not None:
             self._act(mask)
             assert mask.shape == dx.shape
-        check(self.lib.dg_linear_dx(self.dg, out_dg, _ptr(dy), dy.stride(0), _ptr(w), w.stride(0), _ptr(dx), dx.stride(0),
-                                    _ptr(mask), mask.stride(0) if mask is not None else 0, float(mask_slope), B, O, K,
-                                    self._stream()), "dg_linear_dx")
+        es = w.element_size()
+        check(self._timed("lin_dx", 2.0 * B * (o_real or O) * K, lambda: self.lib.dg_linear_dx(
+            self.dg, out_dg, _ptr(dy), dy.stride(0), _ptr(w), w.stride(0), _ptr(dx), dx.stride(0),
+            _ptr(mask), mask.stride(0) if mask is not None else 0, float(mask_slope), B, O, K, self._stream()),
+            float(es * O * K + dx.element_size() * B * K * (2 if mask is not None else 1)), net), "dg_linear_dx")
 
-    def linear_dw(self, dy, x, dw):
+    def linear_dw(self, dy, x, dw, o_real=0, net=""):
         """dw[O,K] (fp32) += dy[B,O]^T @ x[B,K]"""
         self._act(x)
         B, K = x.shape
         O = dw.shape[0]
         assert dy.dtype == torch.float32 and dy.shape[0] == B and dy.shape[1] >= O and dw.dtype == torch.float32 and dw.shape[1] == K
-        check(self.lib.dg_linear_dw(self.dg, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dw.stride(0), B, O, K,
-                                    self._stream()), "dg_linear_dw")
+        check(self._timed("lin_dw", 2.0 * B * (o_real or O) * K, lambda: self.lib.dg_linear_dw(
+            self.dg, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dw.stride(0), B, O, K, self._stream()),
+            float(x.element_size() * B * K + 8.0 * O * K), net), "dg_linear_dw")
 
     def bias_act(self, inp, bias, out, act=None, mask=None, mask_slope=1.0):
         rows, Cc = out.shape
@@ -269,9 +281,9 @@ class HipOps:
         out_dg = _lib.DG_F32 if out.dtype == torch.float32 else self.dg
         if mask is not None:
             assert mask.dtype == out.dtype
-        check(self.lib.dg_bias_act(out_dg, _ptr(inp), inp.stride(0), _ptr(bias), _ptr(out), out.stride(0), rows, Cc,
-                                   int(act is not None), float(act or 1.0), _ptr(mask), mask.stride(0) if mask is not None else 0,
-                                   float(mask_slope), self._stream()), "dg_bias_act")
+        check(self._timed("ew_bias_act", 0.0, lambda: self.lib.dg_bias_act(
+            out_dg, _ptr(inp), inp.stride(0), _ptr(bias), _ptr(out), out.stride(0), rows, Cc, int(act is not None), float(act or 1.0),
+            _ptr(mask), mask.stride(0) if mask is not None else 0, float(mask_slope), self._stream()), 0.0, "C"), "dg_bias_act")
 
     # ------------------------------------------------------------------ elementwise / reductions
     def mask_mul(self, u, y, slope):
@@ -291,18 +303,22 @@ class HipOps:
         for t in (real, fake, xhat):
             self._act(t); assert t.is_contiguous() and t.shape == real.shape
         assert alpha.dtype == torch.float32 and alpha.numel() == real.shape[0]
-        check(self.lib.dg_gp_interp(self.dg, _ptr(real), _ptr(fake), _ptr(alpha), _ptr(xhat), real.shape[0], real[0].numel(), self._stream()), "dg_gp_interp")
+        check(self._timed("ew_gp_interp", 0.0, lambda: self.lib.dg_gp_interp(
+            self.dg, _ptr(real), _ptr(fake), _ptr(alpha), _ptr(xhat), real.shape[0], real[0].numel(), self._stream()),
+            3.0 * real.numel() * real.element_size(), "C"), "dg_gp_interp")
 
     def sumsq_rows(self, g, ss):
         self._act(g); assert g.is_contiguous() and ss.dtype == torch.float32
-        check(self.lib.dg_sumsq_rows(self.dg, _ptr(g), g.shape[0], g[0].numel(), _ptr(ss), self._stream()), "dg_sumsq_rows")
+        check(self._timed("ew_sumsq_rows", 0.0, lambda: self.lib.dg_sumsq_rows(
+            self.dg, _ptr(g), g.shape[0], g[0].numel(), _ptr(ss), self._stream()), 1.0 * g.numel() * g.element_size(), "C"), "dg_sumsq_rows")
 
     def gp_finish(self, ss, B, B_global, gp_lambda, weight, coef, scalar_out):
         check(self.lib.dg_gp_finish(_ptr(ss), B, B_global, float(gp_lambda), float(weight), _ptr(coef), _ptr(scalar_out), self._stream()), "dg_gp_finish")
 
     def scale_rows(self, g, coef, out):
         self._act(g); self._act(out); assert g.is_contiguous() and out.is_contiguous()
-        check(self.lib.dg_scale_rows(self.dg, _ptr(g), _ptr(coef), _ptr(out), g.shape[0], g[0].numel(), self._stream()), "dg_scale_rows")
+        check(self._timed("ew_scale_rows", 0.0, lambda: self.lib.dg_scale_rows(
+            self.dg, _ptr(g), _ptr(coef), _ptr(out), g.shape[0], g[0].numel(), self._stream()), 2.0 * g.numel() * g.element_size(), "C"), "dg_scale_rows")
 
     def l1(self, a, b, acc, grad=None, grad_scale=0.0, addend=None):
         self._act(a); self._act(b)

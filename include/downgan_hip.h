@@ -17,7 +17,9 @@
  *  - Ownership: the caller owns every buffer (incl. workspaces); nothing here allocates or frees
  *    device memory.  Launches are asynchronous on `stream` (a hipStream_t passed as void*).
  *  - Errors: 0 = DG_OK, negative = dg_status; no exceptions cross the ABI.
- *  - Re-entrant; no global mutable state.
+ *  - Re-entrant.  The only mutable state is a per-kernel, per-device "function attributes configured" mask
+ *    (hipFuncAttributeMaxDynamicSharedMemorySize is set once per device) and cached occupancy answers, both
+ *    std::atomic; the device that is current when an entry point is called must be the device of `stream`.
  */
 #ifndef DOWNGAN_HIP_H
 #define DOWNGAN_HIP_H

@@ -181,18 +181,18 @@ class EmuOps:
             dst.copy_(m.permute(2, 1, 0).reshape(-1).to(dst.dtype))
 
     # ------------------------------------------------------------------ linear family
-    def linear_fwd(self, x, w, y):
+    def linear_fwd(self, x, w, y, o_real=0, net=""):
         O = w.shape[0]
         y[:, :O] += x.float() @ w.float().t()
 
-    def linear_dx(self, dy, w, dx, mask=None, mask_slope=1.0):
+    def linear_dx(self, dy, w, dx, mask=None, mask_slope=1.0, o_real=0, net=""):
         O = w.shape[0]
         v = dy[:, :O] @ w.float()
         if mask is not None:
             v = v * _lgrad(mask.float(), mask_slope)
         dx.copy_(v.to(dx.dtype))
 
-    def linear_dw(self, dy, x, dw):
+    def linear_dw(self, dy, x, dw, o_real=0, net=""):
         O = dw.shape[0]
         dw += dy[:, :O].t() @ x.float()
 

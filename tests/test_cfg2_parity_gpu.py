@@ -1,0 +1,177 @@
+"""Parity at BASELINE.json configs[1] SHAPES (2ch 128x128 -> 1024x1024, filters 128, 16 RRDBs; reference
+DoWnGAN/GAN/wasserstein.py:27-117, networks/generator.py:56-90, networks/critic.py:9-106), batch 1, against the pinned CPU
+oracle -- no golden fixture exists at this size (the reference cannot travel and minutes of CPU work per step):
+
+* fp32-parity mode: every scalar within 1e-4 relative; the FULL gradient of every critic parameter (8 convs incl. the
+  512/1024-channel ones, both Linears incl. FC1's 4.19 M columns) and of the generator's parameters against the float64
+  evaluation of the oracle, bounded by the fp32 oracle's own error against float64 (rule of test_step_gpu.py).
+* bf16 throughput mode (the benchmarked precision) against the oracle fed the SAME bf16-rounded weights and inputs: the
+  relative errors are asserted AND written to profiles/bf16_drift_cfg2.json (and gpurun_out/ for the trip home).
+* configs[3]'s 6-covariate input at the full tile (fp32, scalars).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from downgan_amd import synthetic
+from downgan_amd.engine import HyperParams, TrainEngine
+from downgan_amd.ops import HipOps
+from oracle import ref_step
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B, S, F_, NRB = 1, 128, 128, 16
+
+
+def _threads():
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        n = max(1, int(int(quota) / int(period))) if quota != "max" else os.cpu_count()
+    except Exception:
+        n = os.cpu_count()
+    torch.set_num_threads(min(n, os.cpu_count()))
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(a), abs(b), 1e-30)
+
+
+def _inputs(cin, rounded=False):
+    pg = {k: torch.from_numpy(v) for k, v in synthetic.generator_params(F_, cin, 2, NRB).items()}
+    pc = {k: torch.from_numpy(v) for k, v in synthetic.critic_params(F_, 8 * S, 2).items()}
+    coarse, fine = synthetic.tiles(B, cin, S, mask_channel=(2 if cin > 2 else None))
+    tc, tf = torch.from_numpy(coarse), torch.from_numpy(fine)
+    if rounded:
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        pg = {k: r(v) for k, v in pg.items()}
+        pc = {k: r(v) for k, v in pc.items()}
+        tc, tf = r(tc), r(tf)
+    return pg, pc, tc, tf
+
+
+def _engine(dtype, cin, pg, pc, tc, tf):
+    ops = HipOps(dtype)
+    eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B), num_res_blocks=NRB)
+    eng.G.load_state_dict(pg)
+    eng.C.load_state_dict(pc)
+    xc = ops.zeros(B, S, S, eng.G.cin_p); ops.nchw_to_nhwc(tc.cuda(), xc)
+    xf = ops.zeros(B, 8 * S, 8 * S, eng.G.np_p); ops.nchw_to_nhwc(tf.cuda(), xf)
+    return eng, xc, xf
+
+
+def _oracle(pg, pc, tc, tf, dt=torch.float32):
+    """one critic iteration + one generator iteration (no update): scalars and gradients."""
+    _threads()
+    orc = ref_step.OracleTrainer({k: v.to(dt) for k, v in pg.items()}, {k: v.to(dt) for k, v in pc.items()},
+                                 ref_step.HP(batch_size=B), num_res_blocks=NRB)
+    alpha = torch.from_numpy(synthetic.alpha(B, 0))
+    sc, cg = orc.critic_iteration(tc.to(dt), tf.to(dt), alpha.to(dt), apply_update=False)
+    sg, gg = orc.generator_iteration(tc.to(dt), tf.to(dt), apply_update=False)
+    return dict(sc, **sg), cg, gg
+
+
+def _native(dtype, cin, pg, pc, tc, tf):
+    eng, xc, xf = _engine(dtype, cin, pg, pc, tc, tf)
+    alpha = torch.from_numpy(synthetic.alpha(B, 0)).cuda()
+    eng.critic_iteration(xc, xf, alpha, apply_update=False, save_g=True)
+    cg = eng.C.grad_dict()
+    eng.generator_iteration(xc, xf, apply_update=False, reuse_fake=True)      # the step's own schedule: one G(coarse) for both
+    gg = eng.G.grad_dict()
+    sc = eng.read_scalars(True)
+    del eng
+    torch.cuda.empty_cache()
+    return sc, cg, gg
+
+
+@pytest.fixture(scope="module")
+def cfg2_f32():
+    pg, pc, tc, tf = _inputs(2)
+    return dict(o32=_oracle(pg, pc, tc, tf), native=_native("f32", 2, pg, pc, tc, tf), inputs=(pg, pc, tc, tf))
+
+
+SCALARS = ("c_real_mean", "c_fake_mean", "gp_ret", "critic_loss", "g_loss", "content_loss", "g_c_fake_mean")
+
+
+def test_fp32_scalars_full_tile(cfg2_f32):
+    ref, got = cfg2_f32["o32"][0], cfg2_f32["native"][0]
+    for k in SCALARS:
+        assert rel(got[k], ref[k]) < 1e-4, (k, got[k], ref[k])
+
+
+def test_fp32_gradients_full_tile_vs_float64_oracle(cfg2_f32):
+    """every parameter gradient of the critic (wide-channel weight-gradient kernels, FC1 lin_dw at K = 4 194 304) and of the
+    generator at cfg2 widths: ||native - o64|| / ||o64|| <= 2e-5 + 5 x (the fp32 oracle's own error), norms within 1e-4."""
+    pg, pc, tc, tf = cfg2_f32["inputs"]
+    _, cg64, gg64 = _oracle(pg, pc, tc, tf, torch.float64)
+    _, cg32, gg32 = cfg2_f32["o32"]
+    _, cgn, ggn = cfg2_f32["native"]
+    report = {}
+    for name, g64, g32, gn in (("C", cg64, cg32, cgn), ("G", gg64, gg32, ggn)):
+        for k, g in g64.items():
+            den = float(g.norm()) + 1e-30
+            err = float((gn[k].double() - g).norm()) / den
+            ref_err = float((g32[k].double() - g).norm()) / den
+            nrm = rel(float(gn[k].double().norm()), float(g.norm()))
+            report[f"{name}.{k}"] = (err, ref_err, nrm)
+            assert err < 2e-5 + 5 * ref_err, (name, k, err, ref_err)
+            assert nrm < 1e-4 + 5 * ref_err, (name, k, nrm)
+    worst = sorted(report.items(), key=lambda kv: -kv[1][0])[:6]
+    print("fp32 gradient parity at cfg2 widths (rel err native, rel err fp32 oracle, norm rel):", worst)
+    _dump("fp32_grad_parity_cfg2.json", {"what": "||g_native_f32 - g_oracle_f64|| / ||g_oracle_f64|| per parameter, B=1, 2ch 128->1024, F=128, 16 RRDBs",
+                                         "critic": {k[2:]: {"native": v[0], "oracle_f32": v[1]} for k, v in report.items() if k.startswith("C.")},
+                                         "generator_worst": {k[2:]: {"native": v[0], "oracle_f32": v[1]} for k, v in worst if k.startswith("G.")},
+                                         "generator_max": max(v[0] for k, v in report.items() if k.startswith("G."))})
+
+
+def _dump(name, obj):
+    for d in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, name), "w") as f:
+                json.dump(obj, f, indent=1)
+        except OSError:
+            pass
+
+
+# observed on MI355X (profiles/bf16_drift_cfg2.json) x3, see the test below
+BF16_BOUND = {"c_real_mean": 2e-2, "c_fake_mean": 2e-2, "gp_ret": 2e-2, "critic_loss": 2e-2, "g_loss": 2e-2, "content_loss": 2e-2,
+              "g_c_fake_mean": 2e-2}
+
+
+def test_bf16_vs_oracle_on_rounded_inputs_full_tile():
+    """The benchmarked precision against the ORACLE (not against the native fp32 mode): same bf16-rounded weights and
+    inputs on both sides, so what is measured is the bf16 storage of activations / adjoints and the MFMA accumulation."""
+    pg, pc, tc, tf = _inputs(2, rounded=True)
+    ref, cg, gg = _oracle(pg, pc, tc, tf)
+    got, cgn, ggn = _native("bf16", 2, pg, pc, tc, tf)
+    drift = {k: rel(got[k], ref[k]) for k in SCALARS}
+    # the means are O(0.1) differences of O(1) terms: report them on the scale of the critic's output too
+    grads = {}
+    for name, g_ref, g_nat in (("C", cg, cgn), ("G", gg, ggn)):
+        errs = {k: float((g_nat[k] - g).norm() / (g.norm() + 1e-30)) for k, g in g_ref.items()}
+        grads[name] = {"max_rel_l2": max(errs.values()), "argmax": max(errs, key=errs.get),
+                       "median_rel_l2": sorted(errs.values())[len(errs) // 2]}
+        if name == "C":
+            grads[name]["per_param"] = errs
+    _dump("bf16_drift_cfg2.json", {"what": "bf16 engine vs CPU oracle (fp32) on identical bf16-rounded weights/inputs; B=1, 2ch 128x128->1024x1024, "
+                                           "F=128, 16 RRDBs; one critic + one generator iteration; relative errors",
+                                   "scalars": drift, "native": {k: got[k] for k in SCALARS}, "oracle": {k: ref[k] for k in SCALARS},
+                                   "gradients_rel_l2": grads})
+    print("bf16 vs oracle at cfg2 shapes:", {k: f"{v:.2e}" for k, v in drift.items()}, grads["C"]["max_rel_l2"], grads["G"]["max_rel_l2"])
+    for k, v in drift.items():
+        assert v < BF16_BOUND[k], (k, v, got[k], ref[k])
+    assert grads["C"]["max_rel_l2"] < 0.1 and grads["G"]["max_rel_l2"] < 0.1, grads
+
+
+def test_cfg4_six_channel_full_tile_fp32():
+    """BASELINE configs[3]: 6-covariate input (stage.py:50-60) at the full 128 -> 1024 tile; generator conv1 then runs the
+    16-channel-padded wide path instead of the 2-channel im2col kernel.  Scalars within 1e-4 of the oracle."""
+    pg, pc, tc, tf = _inputs(6)
+    ref, _, gg = _oracle(pg, pc, tc, tf)
+    got, _, ggn = _native("f32", 6, pg, pc, tc, tf)
+    for k in SCALARS:
+        assert rel(got[k], ref[k]) < 1e-4, (k, got[k], ref[k])
+    k = "conv1.weight"       # the layer that differs from cfg2
+    assert float((ggn[k] - gg[k]).norm() / gg[k].norm()) < 2e-3, k

@@ -41,6 +41,7 @@ def _worker(rank, world, port, outdir):
     xc, xf, alpha = _data(rank, rank + 1)
     metrics = eng.metrics_pass(xc, xf)          # before the update: global-batch min/max (all-reduce MIN/MAX) and means
     ran_g = eng.train_step(xc, xf, alpha)       # step 0: critic + generator update
+    assert eng.G.P._pending is not None         # the generator update is parked behind the next critic iteration's real pass
     eng.train_step(xc, xf, alpha)               # step 1: critic only; its deferred all-reduce + Adam complete in state_dict()
     assert eng.C.P._pending is not None         # the critic update is parked behind the (next) generator forward
     scal = eng.read_scalars(ran_g)

@@ -1,0 +1,76 @@
+"""Data-parallel path on the GPU: 2 fresh rank processes (torch.distributed.run) against one process with the whole batch.
+
+* ``test_two_nccl_ranks_equal_single_process``: one rank per GPU, gradient exchange over RCCL (``nccl`` backend) --
+  needs >= 2 GPUs and is skipped on the one-GPU box; this is the path bench.py --gpus N runs.
+* ``test_two_ranks_on_one_gpu_rehearsal``: the same two processes sharing cuda:0 with the exchange over gloo, so the
+  multi-process HIP path (flat-buffer all-reduce, deferred updates, sharded metrics) is exercised on every GPU box.
+The rank processes are CHILD processes started before they touch the GPU; nothing re-execs an initialised process.
+"""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(backend, dtype, outdir, n=2):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "dist_worker.py"), backend, outdir, dtype]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [torch.load(os.path.join(outdir, f"r{i}.pt")) for i in range(n)]
+
+
+def _single(dtype):
+    import dist_worker as dw
+    eng, ops = dw.build(2, 2, dtype, "cuda:0")
+    xc, xf, alphas = dw.data(ops, eng, 0, 2, 2)
+    return dw.run(eng, xc, xf, alphas)
+
+
+def _compare(ranks, ref):
+    r0, r1 = ranks
+    lr, steps = 2.5e-4, 2
+    # step 0 is a generator step: both updates were parked behind the next forward (overlap with the all-reduce)
+    assert r0["pending"][0] == (True, True) and r0["pending"][1] == (True, False), r0["pending"]
+    for k in ref["C"]:
+        assert torch.equal(r0["C"][k], r1["C"][k]), k                                  # replicas stay identical
+        assert torch.allclose(r0["C"][k], ref["C"][k], rtol=0, atol=2 * lr * steps), (k, float((r0["C"][k] - ref["C"][k]).abs().max()))
+        assert float((r0["C"][k] - ref["C"][k]).norm()) <= 2e-4 * float(ref["C"][k].norm()) + 1e-6, k
+    for k in ref["G"]:
+        assert torch.equal(r0["G"][k], r1["G"][k]), k
+        assert torch.allclose(r0["G"][k], ref["G"][k], rtol=0, atol=0.25 * lr), k
+    for rec in ("scal0", "scal"):
+        for k, v in ref[rec].items():
+            assert abs(r0[rec][k] - v) <= 2e-5 * max(1.0, abs(v)), (rec, k, r0[rec][k], v)
+            assert r0[rec][k] == r1[rec][k], (rec, k)
+    for k in ("MAE", "MSE", "Wass", "MSSSIM"):
+        assert r0["metrics"][k] == r1["metrics"][k], k
+        assert abs(r0["metrics"][k] - ref["metrics"][k]) <= 1e-5 * max(1.0, abs(ref["metrics"][k])), k
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL ranks cannot share a device)")
+def test_two_nccl_ranks_equal_single_process():
+    with tempfile.TemporaryDirectory() as d:
+        ranks = _launch("nccl", "f32", d)
+    _compare(ranks, _single("f32"))
+
+
+def test_two_ranks_on_one_gpu_rehearsal():
+    with tempfile.TemporaryDirectory() as d:
+        ranks = _launch("gloo", "f32", d)
+    _compare(ranks, _single("f32"))

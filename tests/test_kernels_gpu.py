@@ -61,6 +61,10 @@ CONVS = [
     (1, 64, 64, 256, 128, 2, False),    # stride 2, Wo % 32 == 0, >= 256 input channels: wide DMA-staged weight-gradient kernel
     (2, 64, 128, 320, 192, 2, False),   # ... ragged channel tiles, two images, Wo = 64
     (1, 32, 64, 384, 256, 1, False),    # stride-1 wide weight-gradient kernel: 3 input-channel tiles, 2 adjoint tiles
+    # the critic's widest layers at BASELINE configs[1] widths (critic.py:52-88 with cd = 128): 4 / 8 channel tiles on both sides
+    (1, 64, 64, 512, 512, 2, False),    # features.10
+    (1, 32, 32, 512, 1024, 1, False),   # features.12
+    (1, 64, 64, 1024, 1024, 2, False),  # features.14
 ]
 
 
@@ -151,7 +155,8 @@ def test_conv_slab_views_f32():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("B,K,O", [(4, 8192, 112), (2, 512, 112), (32, 4096, 112), (4, 128, 16), (33, 1024, 16)])
+@pytest.mark.parametrize("B,K,O", [(4, 8192, 112), (2, 512, 112), (32, 4096, 112), (4, 128, 16), (33, 1024, 16),
+                                   (2, 4194304, 112)])    # FC1 of BASELINE configs[1]: 1024 ch x 64 x 64 columns (critic.py:95)
 def test_linear(dtype, B, K, O):
     hip, emu = pair(dtype)
     g = torch.Generator().manual_seed(7)

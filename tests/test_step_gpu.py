@@ -155,32 +155,7 @@ def test_forward_drop_in_modules():
     assert torch.allclose(G.generate(series, chunk_size=2), whole, atol=1e-6)
 
 
-def test_full_tile_fp32_parity_cfg2_shapes():
-    """BASELINE.json configs[1] shapes (2ch 128x128 -> 1024x1024, filters 128, 16 RRDBs) at batch 1 in
-    fp32-parity mode against the CPU oracle: one critic iteration + one generator iteration (no golden
-    fixture exists at this size; the oracle is the pinned restatement).  ~1 min of CPU work."""
-    import os
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        ncpu = max(1, int(int(quota) / int(period))) if quota != "max" else os.cpu_count()
-    except Exception:
-        ncpu = os.cpu_count()
-    torch.set_num_threads(min(ncpu, os.cpu_count()))
-    B, S, F_, cin, nrb = 1, 128, 128, 2, 16
-    eng, pg, pc, tc, tf, xc, xf = make(B, S, F_, cin, nrb, "f32")
-    orc = ref_step.OracleTrainer({k: torch.from_numpy(v) for k, v in pg.items()}, {k: torch.from_numpy(v) for k, v in pc.items()},
-                                 ref_step.HP(batch_size=B), num_res_blocks=nrb)
-    alpha = torch.from_numpy(synthetic.alpha(B, 0))
-    ref, _ = orc.critic_iteration(tc, tf, alpha, apply_update=False)
-    eng.critic_iteration(xc, xf, alpha.cuda(), apply_update=False)
-    got = eng.read_scalars()
-    for k in ("c_real_mean", "c_fake_mean", "gp_ret", "critic_loss"):
-        assert rel(got[k], ref[k]) < 1e-4, (k, got[k], ref[k])
-    refg, _ = orc.generator_iteration(tc, tf, apply_update=False)
-    eng.generator_iteration(xc, xf, apply_update=False)
-    got = eng.read_scalars(True)
-    for k in ("g_loss", "content_loss", "g_c_fake_mean"):
-        assert rel(got[k], refg[k]) < 1e-4, (k, got[k], refg[k])
+# (full-tile parity at BASELINE configs[1] shapes -- scalars, every gradient, bf16 vs the oracle -- lives in test_cfg2_parity_gpu.py)
 
 
 def test_bf16_drift_at_full_tile_vs_fp32_native():

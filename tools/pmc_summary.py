@@ -2,7 +2,10 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
-    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01f_pmc_traffic.json
+    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic_cfg2_bf16.json
+
+The output records the sha256 of the libdowngan_hip.so the passes ran with (run this ON THE BOX, right after the passes, or
+anywhere with the same in-tree build): bench.py reports `roofline.traffic` only when that hash equals the library it loads.
 
 FETCH_SIZE and WRITE_SIZE are in KiB and need separate passes (TCC slots); on gfx950 FETCH_SIZE counts
 128-B read requests as 64 B, so reads are doubled (MI355X_MICROARCH.md, HBM section):
@@ -45,8 +48,17 @@ def main():
         wr = wt.get(k, 0.0) * 1024 / max(wc.get(k, 0), 1)
         res[k] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                   "traffic_bytes_per_launch": rd + wr}
-    json.dump({"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 read correction)", "kernels": res},
-              open(out, "w"), indent=1)
+    import hashlib
+    import os
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "downgan_amd", "csrc", "libdowngan_hip.so")
+    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()
+    try:
+        commit = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(lib)).stdout.strip() or None
+    except Exception:
+        commit = None
+    json.dump({"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 read correction)", "lib_sha256": sha,
+               "commit_at_summary": commit, "kernels": res}, open(out, "w"), indent=1)
     for k, v in list(res.items())[:12]:
         print(f"{k[:70]:70s} n={v['launches']:5d} rd={v['read_bytes_per_launch'] / 1e6:9.1f} MB wr={v['write_bytes_per_launch'] / 1e6:9.1f} MB")
 
