@@ -177,6 +177,15 @@ def test_bf16_drift_at_full_tile_vs_fp32_native():
         for k in ("critic_loss", "gp_ret", "c_real_mean", "c_fake_mean"):
             a, b = res["bf16"][step][k], res["f32"][step][k]
             drift[f"{step}:{k}"] = abs(a - b) / max(abs(b), 1e-3)
+    for d in ("profiles", "gpurun_out"):
+        try:
+            os.makedirs(os.path.join(os.path.dirname(GOLD), "..", d), exist_ok=True)
+            with open(os.path.join(os.path.dirname(GOLD), "..", d, "bf16_vs_f32_native_cfg2_b2.json"), "w") as f:
+                json.dump({"what": "bf16 mode vs fp32-parity mode of the native path, 2ch 128->1024, F=128, 16 RRDBs, B=2, 3 train steps "
+                                   "(updates applied: step 0 is before any update); |a-b| / max(|b|, 1e-3)", "drift": drift,
+                           "fp32": res["f32"], "bf16": res["bf16"]}, f, indent=1)
+        except OSError:
+            pass
     print("bf16 vs fp32 native, 128->1024 tile, B=2:", {k: f"{v:.2e}" for k, v in drift.items()})
     print("fp32:", [{k: round(v, 5) for k, v in r.items() if k in ("critic_loss", "gp_ret", "c_real_mean", "c_fake_mean")} for r in res["f32"]])
     assert max(v for k, v in drift.items() if k.startswith("0:")) < 2e-2          # before any update: pure kernel rounding
