@@ -1,6 +1,7 @@
 """Same-named counterparts of the metric / loss functions of the reference (DoWnGAN/GAN/losses.py) for the four that the
-training loop uses (hyperparams.py:38-43 ``metrics_to_calculate``): NCHW tensors in, Python float out, all arithmetic in the
-HIP kernels (no torch fallback; raises without the native library or a GPU).
+training loop uses (hyperparams.py:38-43 ``metrics_to_calculate``): NCHW tensors in, 0-dim fp32 tensor out (the reference's
+caller does ``.detach().cpu().item()`` on every return, mlflow_epoch.py:58-61), all arithmetic in the HIP kernels (no torch
+fallback; raises without the native library or a GPU).
 
   content_loss(hr, fake, device)      losses.py:40-55   nn.L1Loss()            -> dg_l1
   content_MSELoss(hr, fake, device)   losses.py:58-70   nn.MSELoss()           -> dg_sqdiff
@@ -18,7 +19,7 @@ import torch
 
 from .. import layout
 from ..msssim import MsSsim
-from ..ops import HipOps
+from .. import backend
 
 _ops = {}
 _ms = {}
@@ -27,7 +28,7 @@ _ms = {}
 def _o(device=None):
     key = str(device or "cuda:0")
     if key not in _ops:
-        _ops[key] = HipOps("f32", key if key.startswith("cuda") else "cuda:0")
+        _ops[key] = backend.make_ops("f32", key if key.startswith("cuda") else "cuda:0")
     return _ops[key]
 
 
@@ -38,6 +39,11 @@ def _native(o, t):
     return out
 
 
+def _scalar(o, v):
+    """0-dim fp32 tensor on the compute device, like the reference's loss modules return."""
+    return torch.tensor(float(v), dtype=torch.float32, device=o.device)
+
+
 def wass_loss(real, fake, device=None):
     return real - fake
 
@@ -46,14 +52,14 @@ def content_loss(hr, fake, device=None):
     o = _o(device)
     acc = o.zeros(1, dtype=torch.float32)
     o.l1(_native(o, hr), _native(o, fake), acc)
-    return float(acc.item()) / hr.numel()
+    return _scalar(o, float(acc.item()) / hr.numel())
 
 
 def content_MSELoss(hr, fake, device=None):
     o = _o(device)
     acc = o.zeros(1, dtype=torch.float32)
     o.sqdiff(_native(o, hr), _native(o, fake), acc)
-    return float(acc.item()) / hr.numel()
+    return _scalar(o, float(acc.item()) / hr.numel())
 
 
 def SSIM_Loss(x, y, device=None, reduction="mean", window_size=11):
@@ -63,7 +69,7 @@ def SSIM_Loss(x, y, device=None, reduction="mean", window_size=11):
     key = (str(o.device), N, C, H, W)
     if key not in _ms:
         _ms[key] = MsSsim(o, N, H, W, c_real=C)
-    return _ms[key](_native(o, x), _native(o, y))
+    return _scalar(o, _ms[key](_native(o, x), _native(o, y)))
 
 
 def _std_normalised_mse(m, n):
@@ -85,13 +91,13 @@ def _div_vort(hr, fake, device):
 def divergence_loss(hr, fake, device=None):
     """losses.py:119-156 (u = channel 0 differenced along H, v = channel 1 along W)."""
     m, n = _div_vort(hr, fake, device)
-    return _std_normalised_mse(m[:5], n)
+    return _scalar(_o(device), _std_normalised_mse(m[:5], n))
 
 
 def vorticity_loss(hr, fake, device=None):
     """losses.py:158-193."""
     m, n = _div_vort(hr, fake, device)
-    return _std_normalised_mse(m[5:], n)
+    return _scalar(_o(device), _std_normalised_mse(m[5:], n))
 
 
 metrics_to_calculate = {"MAE": content_loss, "MSE": content_MSELoss, "MSSSIM": SSIM_Loss, "Wass": wass_loss}   # hyperparams.py:38-43

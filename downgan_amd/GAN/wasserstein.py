@@ -3,9 +3,9 @@
 ``WassersteinGAN(G, C, G_optimizer, C_optimizer)`` with the same method names and argument meaning.
 Differences, all additive: the iteration methods RETURN the scalars the reference computes and drops
 (:46-50, :74-78); ``alpha`` can be injected into ``_critic_train_iteration`` / ``_gp`` (the reference
-draws it from the device RNG at :91); Adam is the fused native kernel configured from
-``config.hyperparams`` (the optimizer arguments are accepted for signature compatibility and may be
-None).  mlflow logging / plotting of the reference's epoch loop (:140-179) is out of scope.
+draws it from the device RNG at :91); Adam is the fused native kernel; when ``torch.optim.Adam`` objects
+built the reference's way (stage.py:63-64 over ``G.parameters()`` / ``C.parameters()``) are passed, their lr / betas /
+eps are adopted, otherwise ``config.hyperparams`` applies (the arguments may be None).  mlflow logging / plotting of the reference's epoch loop (:140-179) is out of scope.
 """
 from __future__ import annotations
 
@@ -13,7 +13,19 @@ import torch
 
 from ..config import hyperparams as hp
 from ..engine import TrainEngine
-from ..ops import HipOps
+from .. import backend
+
+
+def _adam_config(opt, base):
+    """Hyper-parameters of a ``torch.optim.Adam`` built the reference's way (stage.py:63-64) -> engine HyperParams.  The
+    optimizer object itself never steps: Adam runs as the fused native kernel over the flat parameter buffers."""
+    if opt is None or not hasattr(opt, "param_groups"):
+        return base
+    import dataclasses
+    g = opt.param_groups[0]
+    if type(opt).__name__ != "Adam" or g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+        raise NotImplementedError("the native trainer implements plain Adam (no weight decay / amsgrad), as the reference configures it")
+    return dataclasses.replace(base, lr=float(g["lr"]), beta1=float(g["betas"][0]), beta2=float(g["betas"][1]), eps=float(g["eps"]))
 
 
 class WassersteinGAN:
@@ -30,15 +42,20 @@ class WassersteinGAN:
         B, cin, S, _ = coarse.shape
         if self._engine is None or (self._engine.B, self._engine.S) != (B, S):
             assert self.G.dtype == self.C.dtype
-            ops = HipOps(self.G.dtype, self.G.device)
+            ops = backend.make_ops(self.G.dtype, self.G.device)
             e = TrainEngine(ops, S, self.G.filters, cin, B, hp.as_engine_hp(B), self.G.n_predictands,
                             self.G.num_res_blocks, self.G.num_upsample, dist=self.dist)
             self.G.bind(e.G)
             self.C.bind(e.C)
+            self._adopt_optimizers(e)
             e.num_steps = self.num_steps
             self._engine = e
             self._stage = (ops.zeros(B, S, S, e.G.cin_p), ops.zeros(B, fine.shape[2], fine.shape[3], e.G.np_p))
         return self._engine
+
+    def _adopt_optimizers(self, e):
+        e.adam_hp[id(e.G.P)] = _adam_config(self.G_optimizer, e.hp)
+        e.adam_hp[id(e.C.P)] = _adam_config(self.C_optimizer, e.hp)
 
     def _to_native(self, e, coarse, fine):
         o = e.ops

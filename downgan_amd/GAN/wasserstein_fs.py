@@ -9,7 +9,7 @@ from __future__ import annotations
 
 from ..config import hyperparams as hp
 from ..engine import TrainEngineFS
-from ..ops import HipOps
+from .. import backend
 from .wasserstein import WassersteinGAN
 
 
@@ -18,11 +18,12 @@ class WassersteinGANFS(WassersteinGAN):
         B, cin, S, _ = coarse.shape
         if self._engine is None or (self._engine.B, self._engine.S) != (B, S):
             assert self.G.dtype == self.C.dtype
-            ops = HipOps(self.G.dtype, self.G.device)
+            ops = backend.make_ops(self.G.dtype, self.G.device)
             e = TrainEngineFS(ops, S, self.G.filters, cin, B, hp.as_engine_hp(B), self.G.n_predictands,
                               self.G.num_res_blocks, self.G.num_upsample, dist=self.dist)
             self.G.bind(e.G)
             self.C.bind(e.C)
+            self._adopt_optimizers(e)
             e.num_steps = self.num_steps
             self._engine = e
             self._stage = (ops.zeros(B, S, S, e.G.cin_p), ops.zeros(B, fine.shape[2], fine.shape[3], e.G.np_p))

@@ -1,0 +1,13 @@
+"""The one place where the Python mirrors obtain their compute backend: the HIP kernels behind the C ABI.
+
+There is no other backend in the product (``HipOps`` raises without a GPU or without the built library).  The indirection
+exists so that CPU tests of the HOST logic of the mirrors (tests/test_integration_cpu.py) can substitute the op-contract
+emulation of ``oracle/emu_ops.py`` by patching ``make_ops``; nothing in ``downgan_amd`` ever does.
+"""
+from __future__ import annotations
+
+from .ops import HipOps
+
+
+def make_ops(dtype, device):
+    return HipOps(dtype, device)

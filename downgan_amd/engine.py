@@ -558,6 +558,7 @@ class TrainEngine:
         self.alpha_dev = o.zeros(batch, dtype=torch.float32)
         self.num_steps = 0
         self.n_real_elems = batch * n_predictands * fine * fine
+        self.adam_hp = {}          # id(ParamStore) -> HyperParams whose lr / betas / eps differ from ``hp`` (trainer mirror)
 
     def _sc(self, name):
         i = self.SCALARS.index(name)
@@ -573,13 +574,13 @@ class TrainEngine:
 
             def finish():
                 self.dist.allreduce_finish(works)
-                P.adam_step(self.hp, 1.0)
+                P.adam_step(self.adam_hp.get(id(P), self.hp), 1.0)
             if defer:
                 P.defer(finish)
             else:
                 finish()
         else:
-            P.adam_step(self.hp, 1.0)
+            P.adam_step(self.adam_hp.get(id(P), self.hp), 1.0)
 
     def critic_iteration(self, coarse, fine, alpha, apply_update=True, save_g=False):
         """wasserstein.py:27-55.  coarse/fine: native NHWC tensors; alpha: fp32 [B] on the device

@@ -6,10 +6,11 @@ import torch
 
 from .. import synthetic
 from ..engine import NativeCritic
-from ..ops import HipOps
+from .. import backend
+from ._module import NativeModule
 
 
-class Critic:
+class Critic(NativeModule):
     def __init__(self, coarse_dim, fine_dim, nc, dtype="bf16", device="cuda:0"):
         self.coarse_dim, self.fine_dim, self.nc = coarse_dim, fine_dim, nc
         self.dtype, self.device = dtype, device
@@ -38,7 +39,7 @@ class Critic:
         if self._bound is not None and self._bound.B == B:
             return self._bound
         if B not in self._native:
-            n = NativeCritic(HipOps(self.dtype, self.device), self.coarse_dim, self.fine_dim, self.nc, B)
+            n = NativeCritic(backend.make_ops(self.dtype, self.device), self.coarse_dim, self.fine_dim, self.nc, B)
             n.load_state_dict(self.state_dict())
             self._native[B] = n
         return self._native[B]

@@ -10,10 +10,11 @@ import torch
 
 from .. import synthetic
 from ..engine import NativeGenerator
-from ..ops import HipOps
+from .. import backend
+from ._module import NativeModule
 
 
-class Generator:
+class Generator(NativeModule):
     def __init__(self, filters, fine_dims, channels, n_predictands=2, num_res_blocks=16, num_upsample=3,
                  dtype="bf16", device="cuda:0"):
         self.filters, self.fine_dims, self.channels = filters, fine_dims, channels   # fine_dims unused, as in the reference
@@ -48,7 +49,7 @@ class Generator:
             return self._bound
         key = (B, S)
         if key not in self._native:
-            ops = HipOps(self.dtype, self.device)
+            ops = backend.make_ops(self.dtype, self.device)
             n = NativeGenerator(ops, self.filters, self.channels, B, S, self.n_predictands, self.num_res_blocks, self.num_upsample)
             n.load_state_dict(self.state_dict())
             self._native[key] = n

@@ -81,12 +81,16 @@ def test_identical_fields_give_one_and_size_independent_properties():
 
 
 def test_reference_named_metric_functions():
-    """downgan_amd.GAN.losses mirrors DoWnGAN/GAN/losses.py (NCHW tensors in, float out)."""
+    """downgan_amd.GAN.losses mirrors DoWnGAN/GAN/losses.py: NCHW tensors in, 0-dim tensor out, consumed the way the
+    reference's metrics pass does (mlflow_epoch.py:58-61: ``.detach().cpu().item()``)."""
     from downgan_amd.GAN import losses as L
     x, y = fields(2, 2, 128, 128, seed=4)
-    assert abs(L.content_loss(x, y) - float(torch.nn.functional.l1_loss(x, y))) < 1e-6
-    assert abs(L.content_MSELoss(x, y) - float(torch.nn.functional.mse_loss(x, y))) < 1e-6
-    assert abs(L.SSIM_Loss(x, y) - om.ssim_loss(x, y)) < 2e-5
+    val = lambda t: t.detach().cpu().item()
+    assert torch.is_tensor(L.content_loss(x, y)) and L.content_loss(x, y).dim() == 0
+    assert abs(val(L.content_loss(x, y, "cuda:0")) - float(torch.nn.functional.l1_loss(x, y))) < 1e-6
+    assert abs(val(L.content_MSELoss(x, y)) - float(torch.nn.functional.mse_loss(x, y))) < 1e-6
+    assert abs(val(L.SSIM_Loss(x, y)) - om.ssim_loss(x, y)) < 2e-5
+    assert abs(val(L.wass_loss(torch.tensor(0.5), torch.tensor(0.25), "cuda:0")) - 0.25) < 1e-7
     assert set(L.metrics_to_calculate) == {"MAE", "MSE", "MSSSIM", "Wass"}
 
 
@@ -97,14 +101,14 @@ def test_divergence_and_vorticity_known_answers_and_oracle():
     from downgan_amd.GAN import losses as L
     from oracle import physics
     hr, fake = physics.reference_test_fixture()
-    assert np.isclose(L.divergence_loss(hr, fake), physics.KNOWN["divergence"], atol=physics.KNOWN["atol"])
-    assert np.isclose(L.vorticity_loss(hr, fake), physics.KNOWN["vorticity"], atol=physics.KNOWN["atol"])
-    assert abs(L.divergence_loss(hr, fake) - physics.divergence_loss(hr, fake)) < 1e-6
+    assert np.isclose(L.divergence_loss(hr, fake).item(), physics.KNOWN["divergence"], atol=physics.KNOWN["atol"])
+    assert np.isclose(L.vorticity_loss(hr, fake).item(), physics.KNOWN["vorticity"], atol=physics.KNOWN["atol"])
+    assert abs(L.divergence_loss(hr, fake).item() - physics.divergence_loss(hr, fake)) < 1e-6
     x, y = fields(3, 2, 97, 130, seed=8, noise=0.5)
     for nat, orc in ((L.divergence_loss, physics.divergence_loss), (L.vorticity_loss, physics.vorticity_loss)):
-        a, b = nat(x, y), orc(x, y)
+        a, b = nat(x, y).item(), orc(x, y)
         assert abs(a - b) < 1e-5 * abs(b) + 1e-7, (a, b)
-    assert abs(L.divergence_loss(x, x)) < 1e-9
+    assert abs(L.divergence_loss(x, x).item()) < 1e-9
 
 
 def test_cabi_rejects_bad_arguments():
