@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 from torch.utils.data import Dataset
 
-from .. import layout
+from .. import backend, layout
 from ..ops import HipOps
 
 
@@ -59,19 +59,37 @@ def epoch_indices(n, batch, world, epoch, seed, shuffle=True):
 
 class ResidentLoader:
     def __init__(self, dataset: NetCDFSR, batch_size, shuffle=True, dtype="bf16", device="cuda:0", rank=0, world=1, seed=0,
-                 ops: HipOps = None, stage_chunk=64):
-        self.ops = ops or HipOps(dtype, device)
+                 ops: HipOps = None, stage_chunk=64, _stores=None):
+        self.ops = ops or backend.make_ops(dtype, device)
         o = self.ops
         self.batch, self.shuffle, self.rank, self.world, self.seed = batch_size, shuffle, rank, world, seed
-        self.n = len(dataset)
-        assert self.n >= batch_size * world, "dataset smaller than one global batch"
-        self.cc, self.cf = dataset.coarse.shape[1], dataset.fine.shape[1]
-        self.store_c = self._stage(dataset.coarse, stage_chunk)
-        self.store_f = self._stage(dataset.fine, stage_chunk)
+        if _stores is None:
+            self.store_c = self._stage(dataset.coarse, stage_chunk)
+            self.store_f = self._stage(dataset.fine, stage_chunk)
+        else:
+            self.store_c, self.store_f = _stores
+        self.n = self.store_f.shape[0]
+        assert self.n >= batch_size * world and self.store_c.shape[0] == self.n, "dataset smaller than one global batch"
+        self.cc, self.cf = self.store_c.shape[3], self.store_f.shape[3]
         B = batch_size
-        self.xc = o.zeros(B, dataset.coarse.shape[2], dataset.coarse.shape[3], layout.pad16(self.cc))
-        self.xf = o.zeros(B, dataset.fine.shape[2], dataset.fine.shape[3], layout.pad16(self.cf))
+        self.xc = o.zeros(B, self.store_c.shape[1], self.store_c.shape[2], layout.pad16(self.cc))
+        self.xf = o.zeros(B, self.store_f.shape[1], self.store_f.shape[2], layout.pad16(self.cf))
         self.epoch = 0
+        self.stats = None
+
+    @classmethod
+    def from_fields(cls, coarse_fields: dict, fine_fields: dict, coarse_order, fine_order, batch_size, stats=None, **kw):
+        """Raw per-variable records (``{name: [time, lat, lon] fp32}``, e.g. ERA-Interim covariates and WRF predictands) ->
+        standardised resident stores (GAN/preprocess.py: gen_experiment_datasets.py:195-233 + stage.py:28-31 in two GPU
+        passes) -> loader.  ``stats`` ({"coarse": ..., "fine": ...}) re-uses the TRAIN statistics for a test split."""
+        from . import preprocess
+        ops = kw.pop("ops", None) or backend.make_ops(kw.get("dtype", "bf16"), kw.get("device", "cuda:0"))
+        chunk = kw.get("stage_chunk", 64)
+        sc, st_c = preprocess.stage_standardized(ops, coarse_fields, list(coarse_order), (stats or {}).get("coarse"), chunk=chunk)
+        sf, st_f = preprocess.stage_standardized(ops, fine_fields, list(fine_order), (stats or {}).get("fine"), chunk=chunk)
+        self = cls(None, batch_size, ops=ops, _stores=(sc, sf), **kw)
+        self.stats = {"coarse": st_c, "fine": st_f}
+        return self
 
     def _stage(self, t, chunk):
         """NCHW fp32 (host or device) -> resident [n, H, W, c] in the compute dtype, a bounded chunk at a time."""

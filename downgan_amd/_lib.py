@@ -49,6 +49,13 @@ class MsssimCombine(C.Structure):
     _fields_ = [("inv_count", C.c_float * 5), ("weight", C.c_float * 5)]
 
 
+MAX_FIELDS = 8
+
+
+class FieldPlanes(C.Structure):
+    _fields_ = [("plane", C.c_void_p * MAX_FIELDS), ("mean", C.c_float * MAX_FIELDS), ("inv_std", C.c_float * MAX_FIELDS), ("c", C.c_int)]
+
+
 MINMAX_PARTS = 256
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
@@ -86,6 +93,8 @@ _PROTOS = {
     "dg_msssim_finish": [_vp, _i, _i, C.POINTER(MsssimCombine), _vp, _vp],
     "dg_div_vort_sums": [_i, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp],
     "dg_gather_samples": [_i, _vp, _i64, _i, _vp, _i, _vp, _i, _vp],
+    "dg_moments": [_vp, _i64, _vp, _vp],
+    "dg_stage_fields": [_i, C.POINTER(FieldPlanes), _i64, _vp, _vp],
     "dg_lowpass5": [_i, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp],
     "dg_lowpass5_adjoint": [_i, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp],
 }

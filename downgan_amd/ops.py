@@ -392,6 +392,21 @@ class HipOps:
         check(self.lib.dg_gather_samples(self.dg, _ptr(store), store.shape[1] * store.shape[2], store.shape[3], _ptr(idx), idx.numel(),
                                          _ptr(dst), dst.shape[3], self._stream()), "dg_gather_samples")
 
+    def moments(self, x, acc):
+        """acc[3] (float64, pre-zeroed) += {sum, sum of squares, count} of the non-NaN elements of the fp32 tensor x."""
+        assert x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and acc.dtype == torch.float64 and acc.numel() == 3
+        check(self.lib.dg_moments(_ptr(x), x.numel(), _ptr(acc), self._stream()), "dg_moments")
+
+    def stage_fields(self, planes, mean, inv_std, dst):
+        """dst[p, k] = (planes[k].flat[p] - mean[k]) * inv_std[k]; planes: c fp32 tensors of equal numel, dst: [..., c] store."""
+        c = len(planes)
+        assert 1 <= c <= _lib.MAX_FIELDS and dst.shape[-1] == c and dst.is_contiguous() and dst.dtype == self.tdtype
+        f = _lib.FieldPlanes(c=c)
+        for k, t in enumerate(planes):
+            assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous() and t.numel() * c == dst.numel(), (k, t.shape, dst.shape)
+            f.plane[k], f.mean[k], f.inv_std[k] = t.data_ptr(), float(mean[k]), float(inv_std[k])
+        check(self.lib.dg_stage_fields(self.dg, C.byref(f), planes[0].numel(), _ptr(dst), self._stream()), "dg_stage_fields")
+
     def div_vort_sums(self, hr, fake, sums):
         """sums[10] (float64, pre-zeroed) += moments of the divergence / vorticity of hr and fake (NHWC, channels 0, 1)."""
         self._act(hr); self._act(fake)

@@ -265,6 +265,24 @@ int dg_div_vort_sums(int dtype, const void* hr, int64_t ldhr, const void* fake, 
 int dg_gather_samples(int dtype, const void* src, int64_t HW, int c_real, const int64_t* idx, int B, void* dst, int c_pad,
                       void* stream);
 
+/* Dataset preprocessing of the data feed.
+ * dg_moments: acc[3] (double, pre-zeroed) += { sum, sum of squares, count } over the non-NaN elements of x[n] -- the
+ *   moments behind `xr_standardize_array` (DoWnGAN/helpers/gen_experiment_datasets.py:195-201: da.mean(skipna=True),
+ *   da.std(skipna=True), population std), accumulated chunk by chunk over a field's whole record.  x 16-byte aligned.
+ * dg_stage_fields: dst[p][k] = (plane[k][p] - mean[k]) * inv_std[k] for p < npix, k < c -- the standardisation itself fused
+ *   with the [time, var, lat, lon] staging of DoWnGAN/GAN/stage.py:28-31, written as the HBM-resident [n][H*W][c] store that
+ *   dg_gather_samples reads.  A field that must not be standardised (the binary `land_sea_mask`,
+ *   gen_experiment_datasets.py:208-209) is passed with mean 0 and inv_std 1.  NaNs stay NaNs, as in the reference. */
+#define DG_MAX_FIELDS 8
+typedef struct dg_field_planes {
+  const float* plane[DG_MAX_FIELDS]; /* c device pointers, each [npix] fp32 */
+  float mean[DG_MAX_FIELDS];
+  float inv_std[DG_MAX_FIELDS];
+  int c;
+} dg_field_planes;
+int dg_moments(const float* x, int64_t n, double* acc, void* stream);
+int dg_stage_fields(int dtype, const dg_field_planes* f, int64_t npix, void* dst, void* stream);
+
 /* Frequency-separation variant (DoWnGAN/GAN/wasserstein_fs.py:36-46,73-86, hyperparams.py:31-35):
  * low = AvgPool2d(5, stride 1)(ReplicationPad2d(2)(x)) and/or high = x - low of an NHWC tensor (C padded channels,
  * multiple of 8); either output may be NULL. */

@@ -320,6 +320,20 @@ class EmuOps:
         if shadow is not None:
             shadow.copy_(p.to(shadow.dtype))
 
+    def gather_samples(self, store, idx, dst):
+        dst.zero_()
+        dst[..., :store.shape[3]] = store[idx.long()].to(dst.dtype)
+
+    def moments(self, x, acc):
+        v = x.double().flatten()
+        v = v[~torch.isnan(v)]
+        acc += torch.stack([v.sum(), (v * v).sum(), torch.tensor(float(v.numel()), dtype=torch.float64)])
+
+    def stage_fields(self, planes, mean, inv_std, dst):
+        for k, t in enumerate(planes):
+            dst.view(-1, len(planes))[:, k] = ((t.flatten() - torch.tensor(mean[k], dtype=torch.float32))
+                                               * torch.tensor(inv_std[k], dtype=torch.float32)).to(dst.dtype)
+
     def nchw_to_nhwc(self, src, dst):
         dst.zero_()
         dst[..., :src.shape[1]] = src.permute(0, 2, 3, 1).to(dst.dtype)
