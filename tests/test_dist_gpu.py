@@ -45,8 +45,10 @@ def _single(dtype):
 def _compare(ranks, ref):
     r0, r1 = ranks
     lr, steps = 2.5e-4, 2
-    # step 0 is a generator step: both updates were parked behind the next forward (overlap with the all-reduce)
-    assert r0["pending"][0] == (True, True) and r0["pending"][1] == (True, False), r0["pending"]
+    # (critic update pending, generator update pending) after each step.  Step 0 is a generator step: the critic's update was
+    # completed by the generator iteration's C(fake), the generator's is parked behind step 1's real-sample pass; after step 1
+    # the critic's update is parked behind the next G(coarse): each exchange overlaps with compute that does not need it
+    assert r0["pending"] == [(False, True), (True, False)], r0["pending"]
     for k in ref["C"]:
         assert torch.equal(r0["C"][k], r1["C"][k]), k                                  # replicas stay identical
         assert torch.allclose(r0["C"][k], ref["C"][k], rtol=0, atol=2 * lr * steps), (k, float((r0["C"][k] - ref["C"][k]).abs().max()))
