@@ -188,8 +188,11 @@ def test_bf16_drift_at_full_tile_vs_fp32_native():
             pass
     print("bf16 vs fp32 native, 128->1024 tile, B=2:", {k: f"{v:.2e}" for k, v in drift.items()})
     print("fp32:", [{k: round(v, 5) for k, v in r.items() if k in ("critic_loss", "gp_ret", "c_real_mean", "c_fake_mean")} for r in res["f32"]])
-    assert max(v for k, v in drift.items() if k.startswith("0:")) < 2e-2          # before any update: pure kernel rounding
-    assert all(v < 0.25 for v in drift.values())
+    # bounds = 3 x the drift observed on MI355X (profiles/bf16_vs_f32_native_cfg2_b2.json: step 0 <= 6.5e-5; after one / two
+    # Adam updates of both networks the trajectories separate: means <= 5.4e-3, critic_loss 2e-4 / 3.4e-2)
+    assert max(v for k, v in drift.items() if k.startswith("0:")) < 2e-4          # before any update: pure kernel rounding
+    assert max(v for k, v in drift.items() if k.startswith("1:")) < 1.7e-2
+    assert all(v < 0.1 for v in drift.values())
 
 
 def test_hip_graph_replay_equals_eager():
