@@ -49,6 +49,10 @@ class MsssimCombine(C.Structure):
     _fields_ = [("inv_count", C.c_float * 5), ("weight", C.c_float * 5)]
 
 
+class F8Operands(C.Structure):
+    _fields_ = [("xq", C.c_void_p), ("xs", C.c_void_p), ("ldxq", C.c_int64), ("wq", C.c_void_p), ("ws", C.c_void_p)]
+
+
 MAX_FIELDS = 8
 
 
@@ -93,6 +97,9 @@ _PROTOS = {
     "dg_msssim_finish": [_vp, _i, _i, C.POINTER(MsssimCombine), _vp, _vp],
     "dg_div_vort_sums": [_i, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp],
     "dg_gather_samples": [_i, _vp, _i64, _i, _vp, _i, _vp, _i, _vp],
+    "dg_quant_mxfp8": [_i, _vp, _i64, _i64, _i, _vp, _i64, _vp, _vp],
+    "dg_conv3x3_fwd_f8": [C.POINTER(ConvGeom), C.POINTER(Epilogue), C.POINTER(F8Operands), _vp, _vp],
+    "dg_conv3x3_dgrad_f8": [C.POINTER(ConvGeom), C.POINTER(Epilogue), C.POINTER(F8Operands), _vp, _vp],
     "dg_moments": [_vp, _i64, _vp, _vp],
     "dg_stage_fields": [_i, C.POINTER(FieldPlanes), _i64, _vp, _vp],
     "dg_lowpass5": [_i, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp],

@@ -1312,6 +1312,278 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// MXFP8 version of the four-wave halo kernel (BASELINE configs[4]: the critic's wide layers, critic.py:25-88): operands are
+// OCP E4M3 bytes with one E8M0 scale per 32-channel block in the "paired" block layout of csrc/quant.hip, the MFMA is
+// v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulate, 2x the bf16 rate).  A K-step is still 8 chunks = 128 bytes per
+// patch / weight row, now 128 channels, and the LDS images, swizzles, DMA pieces and patch pipeline are those of
+// gg_halo4w_kernel: a lane's 32-byte operand is chunk g of the row's first and of its second 64-byte half -- exactly the two
+// 16-byte fragments the bf16 kernel feeds to two MFMAs -- so one scaled MFMA replaces two bf16 ones at the same LDS bytes
+// and the same matrix-pipe cycles for twice the channels.  Beside the operands, each K-step needs 4 scale bytes per patch
+// pixel (fetched with the patch into s_ps) and per weight row (a fifth LDS-DMA piece of waves 0/1 into s_ws); lane group g
+// reads byte g.  Output: bf16 through the common epilogue (activations, masks, bit masks as in the bf16 kernel).
+struct F8Args { const unsigned char* xs; const unsigned char* ws; };      // scale strides follow from Cred: Cred/32 per pixel, 9*Cred/32 per weight row
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+
+template <bool S2>
+__global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, const F8Args f, int tiles_x, int tiles_y) {
+  constexpr int EPC = 16, ES = 1;
+  constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
+  constexpr int BC = 128, KC = 8;                                        // 8 chunks per row: 128 fp8 channels
+  constexpr int PITCH = KC * 16 + 16;                                    // 144 B patch rows
+  constexpr int WROW = KC * 16;                                          // 128 B weight rows, chunk c of row r at c ^ ((r >> 1) & 7)
+  constexpr int NPL = (PROWS * KC + 255) / 256;                          // 11 patch chunks per thread
+  constexpr int NWL = BC * KC / 256;                                     // 4 weight pieces per wave and step
+  extern __shared__ __attribute__((aligned(16))) char dsm4f8[];
+  char* const s_patch = dsm4f8;                                // [PROWS][PITCH]
+  char* const s_w = dsm4f8 + PROWS * PITCH;                    // [2][BC][WROW]
+  char* const s_ws = s_w + 2 * BC * WROW;                      // [2][BC] u32: 4 scale bytes of the row's 128-channel K-step
+  char* const s_ps = s_ws + 2 * BC * 4;                        // [PROWS] u32: same for the patch pixels
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tile_c = tile % a.nct;
+  unsigned rest = tile / a.nct;
+  const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
+  const int ty0 = (rest % tiles_y) * TH;
+  const int img = rest / tiles_y;
+  const int c0 = tile_c * BC;
+  const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0,32)
+  const int sy_base = S2 ? (ty0 > 0 ? 2 * (ty0 - 1) : 0) : (ty0 - 1 > 0 ? ty0 - 1 : 0);
+  const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
+  const int ldxs = a.Cred >> 5, ldws = 9 * (a.Cred >> 5);
+  const char* XSb = reinterpret_cast<const char*>(f.xs) + ((long long)img * a.Hs + sy_base) * a.Ws * ldxs;
+  const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
+  const char* WSb = reinterpret_cast<const char*>(f.ws) + (long long)c0 * ldws;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ncbr = a.cch / KC;                    // real 128-channel blocks
+  const int ncb = S2 ? 4 * ncbr : ncbr;           // (plane, channel block) pairs, plane-major
+  const int nsteps = ncbr * a.ntaps;
+  auto plane_of = [&](int vcb) { return S2 ? (int)(vcb >= ncbr) + (int)(vcb >= 2 * ncbr) + (int)(vcb >= 3 * ncbr) : 0; };
+  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : a.ntaps; };
+
+  unsigned woff[NWL];                             // DMA piece i of this wave: rows wave*32 + 8i .. +7, lane = (row, physical chunk)
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    int row = wave * 32 + i * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    row = perm64(row);                              // LDS row holds output channel c0 + perm64(row)
+    if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;
+    woff[i] = (unsigned)((long long)row * a.ldw * ES) + logical * 16;
+  }
+  unsigned wsoff;                                 // scale piece (waves 0 and 1): LDS row wave*64 + lane
+  {
+    int row = perm64((wave & 1) * 64 + lane);
+    if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;
+    wsoff = (unsigned)(row * ldws);
+  }
+  auto tap_code = [&](int vcb, int tap) {
+    const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap;
+    return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
+  };
+  u32x4_t rp[NPL];
+  unsigned rps[2];
+  auto load_patch = [&](int vcb) {
+    const int plane = plane_of(vcb), cb = vcb - plane * ncbr;
+    const int ppy = plane >> 1, ppx = plane & 1;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc((void*)(XSb + cb * 4), 0, (int)DG_OOB_OFF, 0x00020000);
+    int r0v = r0;
+    asm volatile("" : "+v"(r0v));
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0v + 32 * i;
+      const int py = pr / PW, px = pr - py * PW;
+      const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
+      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+      const unsigned off = !ok ? DG_OOB_OFF : (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16;
+      rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                 // scale words of patch rows tid and tid + 256
+      const int pr = tid + 256 * i;
+      const int py = pr / PW, px = pr - py * PW;
+      const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
+      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+      rps[i] = __builtin_amdgcn_raw_buffer_load_b32(rxs, ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * ldxs) : DG_OOB_OFF, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  char* const st_base = s_patch + r0 * PITCH + cc * 16;
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0 + 32 * i;
+      if (pr < PROWS) *reinterpret_cast<uint4*>(st_base + i * 32 * PITCH) = __builtin_bit_cast(uint4, rp[i]);
+    }
+    *reinterpret_cast<unsigned*>(s_ps + tid * 4) = rps[0];
+    if (tid + 256 < PROWS) *reinterpret_cast<unsigned*>(s_ps + (tid + 256) * 4) = rps[1];
+  };
+  typedef int i32x4h_t __attribute__((ext_vector_type(4)));
+  i32x4h_t w_rs, ws_rs;
+  int w_dst0 = 0, ws_dst = 0;
+  auto dma_setup = [&](int vcb, int tap, int slot) {
+    const unsigned code = tap_code(vcb, tap);
+    const int cbr = vcb - plane_of(vcb) * ncbr;
+    const long long wo = (long long)(code >> 4) * a.Cred + cbr * KC * EPC;
+    const unsigned long long wbase = (unsigned long long)(Wb + wo * ES);
+    w_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wbase);
+    w_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(wbase >> 32) & 0xffff);
+    w_rs[2] = (int)DG_OOB_OFF;
+    w_rs[3] = 0x00020000;
+    w_dst0 = __builtin_amdgcn_readfirstlane(
+        (int)(unsigned long long)((__attribute__((address_space(3))) char*)(s_w + slot * (BC * WROW) + (wave * 32) * WROW)));
+    const unsigned long long sbase = (unsigned long long)(WSb + (long long)(code >> 4) * (a.Cred >> 5) + cbr * 4);
+    ws_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)sbase);
+    ws_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(sbase >> 32) & 0xffff);
+    ws_rs[2] = (int)DG_OOB_OFF;
+    ws_rs[3] = 0x00020000;
+    ws_dst = __builtin_amdgcn_readfirstlane(
+        (int)(unsigned long long)((__attribute__((address_space(3))) char*)(s_ws + slot * (BC * 4) + (wave & 1) * 256)));
+  };
+  auto dma_piece = [&](int i) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(w_dst0 + i * 8 * WROW), "v"(woff[i]), "s"(w_rs) : "memory");
+  };
+  // every wave issues the scale piece (waves 2/3 re-write the rows of waves 0/1 with the same bytes), so the per-wave count
+  // of outstanding vector-memory operations -- what the counted s_waitcnt below relies on -- is the same in all four waves
+  auto dma_scales = [&]() {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                 :: "s"(ws_dst), "v"(wsoff), "s"(ws_rs) : "memory");
+  };
+  auto dma_w = [&](int cb, int tap, int slot) {
+    dma_setup(cb, tap, slot);
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) dma_piece(i);
+    dma_scales();
+  };
+  auto barrier_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
+  auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); __syncthreads(); };   // 11 patch chunks + 2 scale words
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const char* fa_k[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) fa_k[kk] = s_w + l15 * WROW + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) * 16);
+  const char* const fb_lane = s_patch + l15 * PITCH + g * 16;
+  const char* const sa_lane = s_ws + l15 * 4 + g;
+  const char* const sb_lane = s_ps + l15 * 4 + g;
+  // a lane's 32-byte operand = chunk g of the row's first and second 64-byte half, assembled into ONE 8-register value right
+  // at the loads (a loop-carried pair of uint4 made the compiler copy every fragment into a fresh tuple: 32 v_mov per step
+  // and the fragments live twice)
+  auto ld32 = [](const char* p0, const char* p1) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(p0), hi = *reinterpret_cast<const uint4*>(p1);
+    i32x8_t o;
+    o[0] = (int)lo.x; o[1] = (int)lo.y; o[2] = (int)lo.z; o[3] = (int)lo.w;
+    o[4] = (int)hi.x; o[5] = (int)hi.y; o[6] = (int)hi.z; o[7] = (int)hi.w;
+    asm volatile("" : "+v"(o));        // pin the value to one 256-bit register tuple (otherwise SROA splits it across the loop phi again)
+    return o;
+  };
+  i32x8_t fb[4];
+  int sb[4];
+  auto read_b = [&](const char* pb, int prow0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fb[i] = ld32(pb + i * PW * PITCH, pb + i * PW * PITCH + 64);
+      sb[i] = *reinterpret_cast<const unsigned char*>(sb_lane + (prow0 + i * PW) * 4);
+    }
+  };
+  auto mma_pair = [&](int pa, int slot, int j0) {          // two weight fragments x four pixel rows
+    i32x8_t fa[2];
+    int sa[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      fa[q] = ld32(fa_k[0] + pa + (j0 + q) * 16 * WROW, fa_k[1] + pa + (j0 + q) * 16 * WROW);
+      sa[q] = *reinterpret_cast<const unsigned char*>(sa_lane + slot * (BC * 4) + (j0 + q) * 64);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[j0 + q][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[q], fb[i], acc[j0 + q][i], 0, 0, 0, sa[q], 0, sb[i]);
+    // the pair's MFMAs stay in front of whatever memory operation follows (an MFMA is not a memory operation, so a plain
+    // memory clobber lets the compiler sink it below the next pair's LDS reads and the patch prefetch, whose 44 registers
+    // then no longer fit and spill one by one behind a full s_waitcnt)
+    asm volatile("" : "+v"(acc[j0][0]), "+v"(acc[j0][1]), "+v"(acc[j0][2]), "+v"(acc[j0][3]),
+                      "+v"(acc[j0 + 1][0]), "+v"(acc[j0 + 1][1]), "+v"(acc[j0 + 1][2]), "+v"(acc[j0 + 1][3]) :: "memory");
+  };
+  auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps_of(c_)) { t_ = 0; ++c_; } };
+  auto patch_row = [&](int vcb_, int tap_) {
+    const unsigned code = tap_code(vcb_, tap_);
+    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
+    return (wave * 4 + 1 + dy) * PW + 1 + dx;
+  };
+
+  load_patch(0);
+  int cb = 0, tap = 0, cbw = 0, tapw = 0;
+  dma_w(0, 0, 0);
+  adv(cbw, tapw);
+  if (nsteps > 1) dma_w(cbw, tapw, 1);
+  adv(cbw, tapw);                    // -> W[2]
+  store_patch();
+  barrier_all();
+  int prow = patch_row(0, 0);
+  int pa = 0;
+  read_b(fb_lane + prow * PITCH, prow);
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    int ntap = tap + 1, ncbn = cb;
+    const int ntaps_cb = ntaps_of(cb);
+    if (ntap == ntaps_cb) { ntap = 0; ncbn = cb + 1; }
+    const bool swap = ntap == 0 && more;
+    const bool patch_now = cb + 1 < ncb && (ntaps_cb == 1 || tap == 0);     // fetch the next block's patch during its predecessor's first step
+    const bool fetch = s + 2 < nsteps;
+    // (the empty asm with a memory clobber keeps the LDS reads of a pair behind the MFMAs of the previous pair also at IR
+    // level: hoisted together they need 32 more registers and the patch prefetch spills)
+    mma_pair(pa, s & 1, 0);
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    mma_pair(pa, s & 1, 2);
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    if (patch_now) load_patch(cb + 1);
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    mma_pair(pa, s & 1, 4);
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    mma_pair(pa, s & 1, 6);
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    // every wave has read all it needs of this step: the barrier frees slot s&1 (and, at a block end, the patch); W[s+1] has landed
+    if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
+    pa = ((s + 1) & 1) * (BC * WROW);
+    prow = patch_row(ncbn < ncb ? ncbn : 0, ntap);
+    if (swap) {                      // channel-block boundary: the single-buffered patch is rewritten, then published
+      store_patch();
+      barrier_all();
+    }
+    if (more) read_b(fb_lane + prow * PITCH, prow);
+    __builtin_amdgcn_sched_barrier(0);
+    if (fetch) { dma_setup(cbw, tapw, s & 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma_piece(q);
+      dma_scales();
+    }
+    adv(cbw, tapw);
+    __builtin_amdgcn_sched_barrier(0);
+    tap = ntap; cb = ncbn;
+  }
+  halo_epilogue<bf16_t, 2>(a, acc, img, ty0, tx0, c0, wave, 0, l15, g);
+}
+
+template <bool S2>
+static int gg_launch_halo4w_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st) {
+  constexpr int LDS_BYTES = 324 * 144 + 2 * 128 * 128 + 2 * 128 * 4 + 324 * 4;
+  DG_SET_MAX_LDS_ONCE((&gg_halo4w_f8_kernel<S2>), LDS_BYTES);
+  const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
+  a.nct = (unsigned)((a.Nout + 127) / 128);
+  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  g_last_kinds |= 32;
+  hipLaunchKernelGGL((gg_halo4w_f8_kernel<S2>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, f, tiles_x, tiles_y);
+  return dg_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Halo kernel for layers with <= 16 output channels (generator conv3.2: 128 -> 2 at 1024^2; the critic's first-layer data
 // gradient in the penalty): HBM-bound, 1/8 of the MFMA work of a 128-wide tile.  The per-tap kernel re-reads every input
 // pixel 9x through L2 (4.9 ms per pass against a 1.7 ms HBM floor); here a 16x16-pixel tile keeps the (16+2)^2 patch of one
@@ -1662,9 +1934,9 @@ static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------ host side
-static int gg_validate(const dg_gg_desc* d) {
+static int gg_validate(const dg_gg_desc* d, bool f8 = false) {
   if (d->dtype != DG_F32 && d->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
-  const int epc = d->dtype == DG_F32 ? 4 : 8;
+  const int epc = f8 ? 16 : d->dtype == DG_F32 ? 4 : 8;
   if (d->N <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Hd <= 0 || d->Wd <= 0) return DG_ERR_BAD_SHAPE;
   if (d->Cred <= 0 || d->Cred % 8 || d->Nout <= 0 || d->Nout % 16) return DG_ERR_BAD_SHAPE;
   if (d->ntaps < 1 || d->ntaps > 9) return DG_ERR_BAD_SHAPE;
@@ -1744,12 +2016,24 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   return gg_launch_t<T, 128, 16, 32, 16>(a, st);
 }
 
+// fp8 launches: only the shapes the four-wave halo kernel takes (the critic's wide layers); everything else is refused
+static int gg_launch_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st) {
+  if (a.cch % 8 || a.Nout <= 64 || a.Hg < 8 || a.Wg < 8 || a.src_ps || a.dst_ps) return DG_ERR_BAD_SHAPE;
+  if (a.sy_mul == 1 && a.sx_mul == 1 && a.Hs == a.Hg && a.Ws == a.Wg) return gg_launch_halo4w_f8<false>(a, f, N, st);
+  if (a.sy_mul == 2 && a.sx_mul == 2 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1) {
+    GGArgs b = a;
+    if (regroup_taps_by_plane(b)) return gg_launch_halo4w_f8<true>(b, f, N, st);
+  }
+  return DG_ERR_BAD_SHAPE;
+}
+
 static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w, void* y, void* stream,
-                            bool im2col_small) {
+                            bool im2col_small, const dg_f8_operands* f8 = nullptr) {
   if (!d || !x || !w || !y) return DG_ERR_BAD_ARG;
-  int rc = gg_validate(d);
+  if (f8 && (d->dtype != DG_BF16 || !f8->xs || !f8->ws || d->Cred % 128)) return DG_ERR_BAD_SHAPE;
+  int rc = gg_validate(d, f8 != nullptr);
   if (rc) return rc;
-  const int epc = d->dtype == DG_F32 ? 4 : 8;
+  const int epc = f8 ? 16 : d->dtype == DG_F32 ? 4 : 8;
   GGArgs a{};
   a.x = x; a.w = w; a.y = y;
   a.ldx = d->lds; a.ldw = d->ldw; a.ldy = d->ldd;
@@ -1781,6 +2065,10 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     if ((a.r1 && a.ldr1 % 4) || (a.r2 && a.ldr2 % 4) || (a.mask && a.ldmask % 4)) return DG_ERR_BAD_SHAPE;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (f8) {
+    F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws};
+    return gg_launch_f8(a, f, d->N, st);
+  }
   static const bool no_im2col = getenv("DG_GG_NOIM2COL") != nullptr;
   if (im2col_small && !no_im2col) return d->dtype == DG_F32 ? gg_launch_im2col<float>(a, st) : gg_launch_im2col<bf16_t>(a, st);
   return d->dtype == DG_F32 ? gg_launch<float>(a, d->N, st) : gg_launch<bf16_t>(a, d->N, st);
@@ -1868,6 +2156,31 @@ extern "C" int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, co
   if (n < 0) return n;
   for (int i = 0; i < n; ++i) {
     int rc = dg_gather_gemm(&d[i], ep, dy, w_dgrad, dx, stream);
+    if (rc) return rc;
+  }
+  return DG_OK;
+}
+
+// MXFP8 operands (csrc/quant.hip), bf16 output / epilogue tensors.  q->ldxq replaces the source's pixel stride of `g`.
+extern "C" int dg_conv3x3_fwd_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* y, void* stream) {
+  if (!q || !g || g->dtype != DG_BF16 || g->pixel_shuffle || g->Cin % 128) return DG_ERR_BAD_SHAPE;
+  dg_gg_desc d[4];
+  g_last_kinds = 0;
+  int n = dg_conv3x3_plan(g, 0, d);
+  if (n < 0) return n;
+  d[0].lds = q->ldxq;
+  return gather_gemm_impl(&d[0], ep, q->xq, q->wq, y, stream, false, q);
+}
+
+extern "C" int dg_conv3x3_dgrad_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* dx, void* stream) {
+  if (!q || !g || g->dtype != DG_BF16 || g->pixel_shuffle || g->Cout % 128 || g->Cin % 16) return DG_ERR_BAD_SHAPE;
+  dg_gg_desc d[4];
+  g_last_kinds = 0;
+  int n = dg_conv3x3_plan(g, 1, d);
+  if (n < 0) return n;
+  for (int i = 0; i < n; ++i) {
+    d[i].lds = q->ldxq;
+    int rc = gather_gemm_impl(&d[i], ep, q->xq, q->wq, dx, stream, false, q);
     if (rc) return rc;
   }
   return DG_OK;

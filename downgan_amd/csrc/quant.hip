@@ -1,0 +1,92 @@
+// MXFP8 quantisation for the fp8 conv path (BASELINE.json configs[4]; reference math: DoWnGAN/networks/critic.py:20-88).
+//
+// Element format OCP FP8 E4M3 (gfx950's native fp8), one shared E8M0 scale (a power of two) per block of 32 reduction
+// channels -- the operand format of v_mfma_scale_f32_16x16x128_f8f6f4.  BLOCK LAYOUT ("paired"): inside every group of 128
+// channels, block g (0..3) holds channels {16g + e} and {64 + 16g + e}, e < 16.  That is the K set lane group g of the
+// scaled MFMA consumes when its 32-byte operand is the 16-byte chunk g of the first and of the second 64-channel half of a
+// 128-byte row -- i.e. the conv kernel keeps the LDS images, swizzles and fragment reads of its bf16 version unchanged --
+// and, in a conv epilogue, both halves of a block sit in ONE lane (16 consecutive channels of each 64-channel wave-tile
+// half), so a producer can form the block maximum without cross-lane traffic.
+// scale byte s: value 2^(s - 127); chosen as 2^(floor(log2(amax)) - 8) (8 = emax of E4M3, OCP MX rule); elements are
+// x / scale rounded to nearest even, saturated at +-448.
+#include "dg_internal.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned int q_u32x4_t;
+
+template <typename T> struct QLoad;
+template <> struct QLoad<bf16_t> {   // 16 channels = 32 bytes
+  static __device__ __forceinline__ void run(const bf16_t* p, float* v) {
+    const q_u32x4_t a = *reinterpret_cast<const q_u32x4_t*>(p), b = *reinterpret_cast<const q_u32x4_t*>(p + 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[2 * q] = __uint_as_float(a[q] << 16); v[2 * q + 1] = __uint_as_float(a[q] & 0xffff0000u);
+      v[8 + 2 * q] = __uint_as_float(b[q] << 16); v[9 + 2 * q] = __uint_as_float(b[q] & 0xffff0000u);
+    }
+  }
+};
+template <> struct QLoad<float> {
+  static __device__ __forceinline__ void run(const float* p, float* v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t = reinterpret_cast<const float4*>(p)[q];
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  }
+};
+
+__device__ __forceinline__ q_u32x4_t pack_fp8x16(const float* v, float inv) {
+  q_u32x4_t o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int w = 0;
+    const float a = __builtin_fminf(__builtin_fmaxf(v[4 * q] * inv, -448.f), 448.f), b = __builtin_fminf(__builtin_fmaxf(v[4 * q + 1] * inv, -448.f), 448.f);
+    const float c = __builtin_fminf(__builtin_fmaxf(v[4 * q + 2] * inv, -448.f), 448.f), d = __builtin_fminf(__builtin_fmaxf(v[4 * q + 3] * inv, -448.f), 448.f);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    o[q] = (unsigned)w;
+  }
+  return o;
+}
+
+// one thread = one block of one row: rows x (C / 32) threads
+template <typename T>
+__global__ void __launch_bounds__(256) quant_mxfp8_kernel(const T* __restrict__ src, long long rows, long long ld, int C,
+                                                          unsigned char* __restrict__ q, long long ldq, unsigned char* __restrict__ sc) {
+  const int nb = C >> 5;
+  const long long total = rows * nb;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long r = t / nb;
+    const int b = (int)(t - r * nb), grp = b >> 2, g = b & 3;
+    const int c_lo = grp * 128 + 16 * g;
+    float v[32];
+    QLoad<T>::run(src + r * ld + c_lo, v);
+    QLoad<T>::run(src + r * ld + c_lo + 64, v + 16);
+    float amax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[k]));
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;          // biased exponent of 2^(floor(log2 amax) - 8)
+    e = e < 0 ? 0 : e;
+    const float inv = __uint_as_float((unsigned)(254 - e) << 23);       // 2^(127 - e), exact
+    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo) = pack_fp8x16(v, inv);
+    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo + 64) = pack_fp8x16(v + 16, inv);
+    sc[r * nb + b] = (unsigned char)e;
+  }
+}
+
+extern "C" int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int64_t ld, int C, void* q, int64_t ldq, void* scales,
+                              void* stream) {
+  if (!src || !q || !scales || rows <= 0 || C <= 0 || C % 128 || ld < C || ldq < C || ldq % 16) return DG_ERR_BAD_SHAPE;
+  if ((src_dtype == DG_BF16 && ld % 8) || (src_dtype == DG_F32 && ld % 4)) return DG_ERR_BAD_SHAPE;
+  const long long total = (long long)rows * (C / 32);
+  long long nb = (total + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (src_dtype == DG_BF16)
+    hipLaunchKernelGGL(quant_mxfp8_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)src, (long long)rows, (long long)ld, C,
+                       (unsigned char*)q, (long long)ldq, (unsigned char*)scales);
+  else if (src_dtype == DG_F32)
+    hipLaunchKernelGGL(quant_mxfp8_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)src, (long long)rows, (long long)ld, C,
+                       (unsigned char*)q, (long long)ldq, (unsigned char*)scales);
+  else return DG_ERR_BAD_DTYPE;
+  return dg_check_launch();
+}

@@ -66,7 +66,10 @@ class HipOps:
 
     name = "hip"
 
-    def __init__(self, dtype="bf16", device="cuda:0"):
+    def __init__(self, dtype="bf16", device="cuda:0", f8_critic=False):
+        """``f8_critic``: MXFP8 conv path (BASELINE configs[4]) -- forward and data-gradient convs of critic layers whose
+        reduction channels are a multiple of 128 run on the block-scaled fp8 MFMA: their bf16 source tensor and weight pack are
+        quantised on the fly (``dg_quant_mxfp8``), accumulation is fp32, outputs / masks / weight gradients stay bf16."""
         assert dtype in TORCH_DTYPE
         if not torch.cuda.is_available():
             raise RuntimeError("downgan_amd.ops.HipOps needs a ROCm GPU (no CPU fallback exists)")
@@ -77,6 +80,9 @@ class HipOps:
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.lib = _lib.lib()
         self.prof = None      # optional list of (tag, flops, bytes, start_event, end_event): bench.py's live kernel timing
+        self.f8 = bool(f8_critic)
+        assert not self.f8 or dtype == "bf16", "the fp8 conv path quantises bf16 tensors"
+        self._f8_scratch = {}
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -184,6 +190,10 @@ class HipOps:
         assert w_fwd.numel() == cv.Cout * 9 * cv.Cin and w_fwd.is_contiguous()
         g = self._geom(cv, pix_layout(x)[0], pix_layout(y)[0])
         e = self._epilogue(y, **ep)
+        if self.f8 and cv.net == "C" and cv.Cin % 128 == 0 and cv.Cout > 64 and not cv.pixel_shuffle:
+            check(self._timed("conv_fwd", self.conv_flops(cv), lambda: self._conv_f8(self.lib.dg_conv3x3_fwd_f8, g, e, x, w_fwd, cv.Cout, cv.Cin, y),
+                              self.conv_bytes(cv, ep), cv.net, self._geom_tag(cv)), "dg_conv3x3_fwd_f8")
+            return
         check(self._timed("conv_fwd", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_fwd(
             C.byref(g), C.byref(e), _ptr(x), _ptr(w_fwd), _ptr(y), self._stream()), self.conv_bytes(cv, ep), cv.net, self._geom_tag(cv)), "dg_conv3x3_fwd")
 
@@ -194,8 +204,48 @@ class HipOps:
         assert w_dgrad.numel() == cv.Cout * 9 * cv.Cin and w_dgrad.is_contiguous()
         g = self._geom(cv, pix_layout(dx)[0], pix_layout(dy)[0])
         e = self._epilogue(dx, **ep)
+        if self.f8 and cv.net == "C" and cv.Cout % 128 == 0 and cv.Cin > 64 and not cv.pixel_shuffle:
+            check(self._timed("conv_dgrad", self.conv_flops(cv), lambda: self._conv_f8(self.lib.dg_conv3x3_dgrad_f8, g, e, dy, w_dgrad, cv.Cin, cv.Cout, dx),
+                              self.conv_bytes(cv, ep), cv.net, self._geom_tag(cv)), "dg_conv3x3_dgrad_f8")
+            return
         check(self._timed("conv_dgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_dgrad(
             C.byref(g), C.byref(e), _ptr(dy), _ptr(w_dgrad), _ptr(dx), self._stream()), self.conv_bytes(cv, ep), cv.net, self._geom_tag(cv)), "dg_conv3x3_dgrad")
+
+    # ------------------------------------------------------------------ MXFP8 conv path
+    def quant_mxfp8(self, src, q=None, scales=None):
+        """src: [..., C] (bf16 or fp32, unit channel stride, dense rows of stride ld) -> (q uint8 [rows, C], scales uint8
+        [rows, C/32]) in the paired-block MXFP8 layout of csrc/quant.hip."""
+        Cc = src.shape[-1]
+        assert Cc % 128 == 0 and src.stride(-1) == 1 and src.is_cuda
+        if src.dim() == 4:
+            ld, rows = pix_layout(src)
+        else:
+            src2 = src.reshape(-1, Cc)
+            assert src2.data_ptr() == src.data_ptr()
+            ld, rows = src2.stride(0), src2.shape[0]
+        if q is None:
+            q = torch.empty(rows, Cc, dtype=torch.uint8, device=self.device)
+            scales = torch.empty(rows, Cc // 32, dtype=torch.uint8, device=self.device)
+        assert q.dtype == torch.uint8 and q.numel() >= rows * Cc and scales.numel() >= rows * (Cc // 32)
+        sdt = _lib.DG_F32 if src.dtype == torch.float32 else _lib.DG_BF16
+        assert src.dtype in (torch.float32, torch.bfloat16)
+        check(self.lib.dg_quant_mxfp8(sdt, _ptr(src), rows, ld, Cc, _ptr(q), Cc, _ptr(scales), self._stream()), "dg_quant_mxfp8")
+        return q, scales
+
+    def _f8_buf(self, key, n):
+        b = self._f8_scratch.get(key)
+        if b is None or b.numel() < n:
+            b = self._f8_scratch[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return b
+
+    def _conv_f8(self, fn, g, e, src, w, nout, cred, dst):
+        """quantise the bf16 source tensor and weight pack into scratch, then the fp8 conv (forward or data gradient)."""
+        rows = src.numel() // cred
+        xq, xs = self.quant_mxfp8(src, self._f8_buf("xq", rows * cred), self._f8_buf("xs", rows * (cred // 32)))
+        wv = w.view(nout * 9, cred)
+        wq, ws = self.quant_mxfp8(wv, self._f8_buf("wq", wv.numel()), self._f8_buf("ws", wv.numel() // 32))
+        q = _lib.F8Operands(xq=xq.data_ptr(), xs=xs.data_ptr(), ldxq=cred, wq=wq.data_ptr(), ws=ws.data_ptr())
+        return fn(C.byref(g), C.byref(e), C.byref(q), _ptr(dst), self._stream())
 
     def conv_wgrad(self, cv: Conv, x, dy, dw, db=None):
         """dw += weight gradient; db (optional, fp32 [Cout]) += bias gradient = column sums of dy."""

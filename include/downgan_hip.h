@@ -265,6 +265,29 @@ int dg_div_vort_sums(int dtype, const void* hr, int64_t ldhr, const void* fake, 
 int dg_gather_samples(int dtype, const void* src, int64_t HW, int c_real, const int64_t* idx, int B, void* dst, int c_pad,
                       void* stream);
 
+/* MXFP8 conv path (BASELINE.json configs[4]: "fp8 (CDNA4 fp8 MFMA) conv path"; reference math of the layers it serves:
+ * DoWnGAN/networks/critic.py:25-88, the critic's seven 128..1024-channel convs).
+ * dg_quant_mxfp8: rows x C values (C % 128 == 0, row stride `ld` elements, dtype DG_BF16 or DG_F32) -> OCP FP8 E4M3 bytes
+ *   q[rows][ldq] + one E8M0 scale byte per 32-channel block, scales[rows][C/32].  Block (c / 128) * 4 + g holds channels
+ *   128*(c/128) + {16g..16g+15} and + 64 + {16g..16g+15} (the K set one lane group of v_mfma_scale_f32_16x16x128_f8f6f4 reads
+ *   in the conv kernel); scale = 2^(floor(log2 amax) - 8), elements = round-to-nearest-even(x / scale) saturated at +-448.
+ *   Serves activations / adjoints (rows = pixels) and conv weight packs (rows = Nout * 9, C = Cred).
+ * dg_conv3x3_fwd_f8 / dg_conv3x3_dgrad_f8: dg_conv3x3_fwd / _dgrad with both MFMA operands in that format and fp32
+ *   accumulation; `g` describes the layer as for the bf16 calls (g->dtype = DG_BF16: the type of y / dx and of every
+ *   epilogue operand), `q` carries the quantised source (xq, xs, pixel stride ldxq bytes) and weight pack (wq, ws: the
+ *   forward pack [Cout][9][Cin] for _fwd, the data-gradient pack [Cin][9][Cout] for _dgrad).  Shapes: reduction channels a
+ *   multiple of 128, more than 64 output channels, no pixel shuffle; anything else returns DG_ERR_BAD_SHAPE. */
+typedef struct dg_f8_operands {
+  const void* xq;   /* fp8 source, NHWC */
+  const void* xs;   /* its scales [pixels][Cred/32] */
+  int64_t ldxq;     /* pixel stride of xq in bytes */
+  const void* wq;   /* fp8 weight pack [Nout][9][Cred] */
+  const void* ws;   /* its scales [Nout][9][Cred/32] */
+} dg_f8_operands;
+int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int64_t ld, int C, void* q, int64_t ldq, void* scales, void* stream);
+int dg_conv3x3_fwd_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* y, void* stream);
+int dg_conv3x3_dgrad_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* dx, void* stream);
+
 /* Dataset preprocessing of the data feed.
  * dg_moments: acc[3] (double, pre-zeroed) += { sum, sum of squares, count } over the non-NaN elements of x[n] -- the
  *   moments behind `xr_standardize_array` (DoWnGAN/helpers/gen_experiment_datasets.py:195-201: da.mean(skipna=True),

@@ -28,7 +28,8 @@ def _lgrad(y, slope):
 class EmuOps:
     name = "emu"
 
-    def __init__(self, dtype="f32", device="cpu"):
+    def __init__(self, dtype="f32", device="cpu", f8_critic=False):
+        self.f8 = bool(f8_critic)
         self.dtype = dtype
         self.tdtype = TORCH_DTYPE[dtype]
         self.dg = DG_DTYPE[dtype]
@@ -138,13 +139,40 @@ class EmuOps:
             full[..., :v.shape[-1]] = y[..., :v.shape[-1]].float() > 0
             self._pack_bits(full, out_bits)
 
+    # ---- MXFP8 (csrc/quant.hip): OCP E4M3 elements, one E8M0 scale per "paired" block of 32 channels -- block g of a
+    # 128-channel group = channels {16g + e} and {64 + 16g + e}, e < 16; scale = 2^(floor(log2 amax) - 8)
+    @staticmethod
+    def mx_quant(x):
+        """x [..., C] -> (q uint8 [rows, C] E4M3 bit patterns, scales uint8 [rows, C/32], dequantised fp32 [..., C])."""
+        Cc = x.shape[-1]
+        assert Cc % 128 == 0
+        v = x.float().reshape(-1, Cc // 128, 2, 4, 16).permute(0, 1, 3, 2, 4).reshape(-1, Cc // 128, 4, 32)
+        amax = v.abs().amax(-1)
+        e = (((amax.contiguous().view(torch.int32) >> 23) & 0xff) - 8).clamp(min=0)
+        scale = torch.ldexp(torch.ones_like(amax), e - 127)
+        q8 = (v / scale[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+        deq = q8.float() * scale[..., None]
+        unblock = lambda t: t.reshape(-1, Cc // 128, 4, 2, 16).permute(0, 1, 3, 2, 4).reshape(-1, Cc)
+        return unblock(q8.view(torch.uint8)), e.to(torch.uint8).reshape(-1, Cc // 32), unblock(deq).reshape(x.shape)
+
+    def quant_mxfp8(self, src, q=None, scales=None):
+        qq, ss, _ = self.mx_quant(src)
+        return qq, ss
+
+    def _f8_eligible(self, cv, cred, nout):
+        return self.f8 and cv.net == "C" and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
+
     def conv_fwd(self, cv: Conv, x, w_fwd, y, **ep):
         assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(y.shape) == self.out_shape(cv)
         (d,) = self._plan(cv, 0, pix_layout(x)[0], pix_layout(y)[0])
+        if self._f8_eligible(cv, cv.Cin, cv.Cout):       # fp8 operands, exact products, fp32 accumulation
+            x, w_fwd = self.mx_quant(x)[2], self.mx_quant(w_fwd.view(cv.Cout * 9, cv.Cin))[2]
         self._gather_gemm(d, x, w_fwd, y, **ep)
 
     def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, **ep):
         assert tuple(dx.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(dy.shape) == self.out_shape(cv)
+        if self._f8_eligible(cv, cv.Cout, cv.Cin):
+            dy, w_dgrad = self.mx_quant(dy)[2], self.mx_quant(w_dgrad.view(cv.Cin * 9, cv.Cout))[2]
         for d in self._plan(cv, 1, pix_layout(dx)[0], pix_layout(dy)[0]):
             self._gather_gemm(d, dy, w_dgrad, dx, **ep)
 

@@ -1,0 +1,121 @@
+"""MXFP8 conv path (BASELINE configs[4]) through the C ABI: dg_quant_mxfp8 bit-exact against the emulation, the fp8
+forward / stride-2 forward / data-gradient convs of the critic's wide layers (critic.py:25-88) against fp32 convolutions of
+the SAME dequantised operands (products of E4M3 values are exact in fp32, so only accumulation order and the bf16 rounding
+of the result differ), and one critic + generator iteration of the engine in fp8 mode against the emulated engine."""
+import pytest
+import torch
+
+from downgan_amd.ops import Conv, HipOps
+from oracle.emu_ops import EmuOps
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, what, tol=1.6e-2):
+    a, b = a.float().cpu(), b.float().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e}) at {(a - b).abs().argmax().item()}"
+
+
+@pytest.mark.parametrize("src_dtype", [torch.bfloat16, torch.float32])
+def test_quantiser_matches_emulation_bit_for_bit(src_dtype):
+    hip = HipOps("bf16")
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(3, 9, 13, 384, generator=g) * torch.logspace(-7, 3, 384)).to(src_dtype)
+    x[0, 0, 0, :128] = 0
+    x[1, 2, 3, 200] = 3e4
+    x[2, :, :, 256:] *= 1e-30                                   # deep underflow: scale byte clamps at 0
+    q_ref, s_ref, _ = EmuOps.mx_quant(x)
+    q, s = hip.quant_mxfp8(x.cuda())
+    assert torch.equal(s.cpu(), s_ref), (s.cpu().int() - s_ref.int()).abs().max()
+    same = q.cpu() == q_ref
+    zeros = (q.cpu() & 0x7f) == 0                               # +0 / -0 are the same value
+    assert bool((same | (zeros & ((q_ref & 0x7f) == 0))).all()), int((~same).sum())
+    # a channel-slice view with a wider pixel stride
+    slab = torch.randn(2, 4, 4, 640, generator=g).to(src_dtype).cuda()
+    q2, s2 = hip.quant_mxfp8(slab[..., 128:384])
+    q2r, s2r, _ = EmuOps.mx_quant(slab[..., 128:384].cpu())
+    assert torch.equal(q2.cpu(), q2r) and torch.equal(s2.cpu(), s2r)
+
+
+F8_CONVS = [
+    # N, H, W, Cin, Cout, stride  -- the critic's wide layers at cfg2 widths (critic.py:25-88), small grids; ragged tiles
+    (1, 32, 32, 128, 128, 2),
+    (1, 32, 32, 128, 256, 1),
+    (2, 48, 80, 256, 256, 2),
+    (1, 32, 32, 256, 512, 1),
+    (1, 32, 32, 512, 512, 2),
+    (1, 16, 16, 512, 1024, 1),
+    (1, 32, 32, 1024, 1024, 2),
+    (2, 24, 40, 128, 192, 1),      # partial output-channel tile
+]
+
+
+@pytest.mark.parametrize("cfg", F8_CONVS)
+def test_fp8_conv_fwd_and_dgrad(cfg):
+    N, H, W, ci, co, st = cfg
+    hip, emu = HipOps("bf16", f8_critic=True), EmuOps("bf16", f8_critic=True)
+    g = torch.Generator().manual_seed(21)
+    cv = Conv(N, H, W, ci, co, st, False, net="C")
+    x = (torch.randn(N, H, W, ci, generator=g) * torch.logspace(-2, 1, ci)).to(torch.bfloat16)
+    w = (torch.randn(co * 9 * ci, generator=g) * 0.05).to(torch.bfloat16)
+    osh = emu.out_shape(cv)
+    # forward: LeakyReLU + out_bits (critic forward) / 1-bit mask (penalty tangent forward)
+    bits_shape = emu.bits_shape(osh) if co % 64 == 0 else None
+    y_ref = torch.zeros(osh, dtype=torch.bfloat16)
+    ob_ref = torch.zeros(bits_shape, dtype=torch.int16) if bits_shape else None
+    emu.conv_fwd(cv, x, w, y_ref, act=0.2, out_bits=ob_ref)
+    y = torch.zeros(osh, dtype=torch.bfloat16).cuda()
+    ob = torch.zeros(bits_shape, dtype=torch.int16).cuda() if bits_shape else None
+    hip.conv_fwd(cv, x.cuda(), w.cuda(), y, act=0.2, out_bits=ob)
+    assert hip.lib.dg_last_conv_kernels() == 32                    # the fp8 kernel served the call
+    close(y, y_ref, f"fp8 fwd {cfg}")
+    if bits_shape:
+        y2_ref, y2 = torch.zeros(osh, dtype=torch.bfloat16), torch.zeros(osh, dtype=torch.bfloat16).cuda()
+        emu.conv_fwd(cv, x, w, y2_ref, mask_bits=ob_ref, mask_slope=0.2)
+        hip.conv_fwd(cv, x.cuda(), w.cuda(), y2, mask_bits=ob_ref.cuda(), mask_slope=0.2)
+        close(y2, y2_ref, f"fp8 fwd mask_bits {cfg}")
+    # data gradient (tiny adjoints, as in the train step: the block scales carry the range)
+    if ci % 64 == 0 and ci > 64:
+        dy = (torch.randn(osh, generator=g) * 1e-4 * torch.logspace(-1, 1, co)).to(torch.bfloat16)
+        wd = (torch.randn(co * 9 * ci, generator=g) * 0.05).to(torch.bfloat16)
+        mb = (torch.randint(0, 1 << 15, emu.bits_shape((N, H, W, ci)), generator=g)).to(torch.int16)
+        dx_ref = torch.zeros(N, H, W, ci, dtype=torch.bfloat16)
+        emu.conv_dgrad(cv, dy, wd, dx_ref, mask_bits=mb, mask_slope=0.2)
+        dx = torch.zeros(N, H, W, ci, dtype=torch.bfloat16).cuda()
+        hip.conv_dgrad(cv, dy.cuda(), wd.cuda(), dx, mask_bits=mb.cuda(), mask_slope=0.2)
+        a, b = dx.float().cpu(), dx_ref.float()
+        assert float((a - b).abs().max()) <= 1.6e-2 * float(b.abs().max()), (cfg, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_fp8_engine_iteration_matches_emulated_engine():
+    """One critic + one generator iteration with the critic's wide convs in fp8, HIP against the emulated engine (bf16
+    storage on both sides); F = 128 so that every critic layer but the first is eligible."""
+    from downgan_amd import synthetic
+    from downgan_amd.engine import HyperParams, TrainEngine
+    from downgan_amd.layout import nchw_to_nhwc_padded
+    torch.set_num_threads(8)
+    B, S, F_, cin, nrb = 1, 16, 128, 2, 1
+    pg, pc = synthetic.generator_params(F_, cin, 2, nrb), synthetic.critic_params(F_, 8 * S, 2)
+    coarse, fine = synthetic.tiles(B, cin, S)
+    alpha = torch.from_numpy(synthetic.alpha(B, 0))
+    res = {}
+    for name in ("emu", "hip"):
+        ops = EmuOps("bf16", f8_critic=True) if name == "emu" else HipOps("bf16", f8_critic=True)
+        eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B), num_res_blocks=nrb)
+        eng.G.load_state_dict(pg); eng.C.load_state_dict(pc)
+        if name == "emu":
+            xc = nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.bfloat16)
+            xf = nchw_to_nhwc_padded(torch.from_numpy(fine), 16, torch.bfloat16)
+            al = alpha
+        else:
+            xc = ops.zeros(B, S, S, 16); ops.nchw_to_nhwc(torch.from_numpy(coarse).cuda(), xc)
+            xf = ops.zeros(B, 8 * S, 8 * S, 16); ops.nchw_to_nhwc(torch.from_numpy(fine).cuda(), xf)
+            al = alpha.cuda()
+        eng.critic_iteration(xc, xf, al, apply_update=False, save_g=True)
+        eng.generator_iteration(xc, xf, apply_update=False, reuse_fake=True)
+        res[name] = eng.read_scalars(True)
+    for k in ("c_real_mean", "c_fake_mean", "gp_ret", "critic_loss", "g_loss", "content_loss"):
+        a, b = res["hip"][k], res["emu"][k]
+        assert abs(a - b) <= 2e-2 * max(abs(b), 0.05), (k, a, b)
