@@ -1313,7 +1313,8 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // MXFP8 version of the four-wave halo kernel (BASELINE configs[4]: the critic's wide layers, critic.py:25-88): operands are
-// OCP E4M3 bytes with one E8M0 scale per 32-channel block in the "paired" block layout of csrc/quant.hip, the MFMA is
+// OCP E4M3 bytes with one E8M0 scale per block of 32 consecutive channels (csrc/quant.hip, which also records how the
+// instruction maps operand bytes and scale lanes to K -- measured with tools/fp8_probe2.hip), the MFMA is
 // v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulate, 2x the bf16 rate).  A K-step is still 8 chunks = 128 bytes per
 // patch / weight row, now 128 channels, and the LDS images, swizzles, DMA pieces and patch pipeline are those of
 // gg_halo4w_kernel: a lane's 32-byte operand is chunk g of the row's first and of its second 64-byte half -- exactly the two

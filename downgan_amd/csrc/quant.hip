@@ -1,12 +1,13 @@
 // MXFP8 quantisation for the fp8 conv path (BASELINE.json configs[4]; reference math: DoWnGAN/networks/critic.py:20-88).
 //
-// Element format OCP FP8 E4M3 (gfx950's native fp8), one shared E8M0 scale (a power of two) per block of 32 reduction
-// channels -- the operand format of v_mfma_scale_f32_16x16x128_f8f6f4.  BLOCK LAYOUT ("paired"): inside every group of 128
-// channels, block g (0..3) holds channels {16g + e} and {64 + 16g + e}, e < 16.  That is the K set lane group g of the
-// scaled MFMA consumes when its 32-byte operand is the 16-byte chunk g of the first and of the second 64-channel half of a
-// 128-byte row -- i.e. the conv kernel keeps the LDS images, swizzles and fragment reads of its bf16 version unchanged --
-// and, in a conv epilogue, both halves of a block sit in ONE lane (16 consecutive channels of each 64-channel wave-tile
-// half), so a producer can form the block maximum without cross-lane traffic.
+// Element format OCP FP8 E4M3 (gfx950's native fp8), one shared E8M0 scale (a power of two) per block of 32 CONSECUTIVE
+// reduction channels (the OCP MX layout) -- the operand format of v_mfma_scale_f32_16x16x128_f8f6f4.  How the instruction
+// maps registers to K (measured with tools/fp8_probe2.hip, not documented in the guides): lane (row r = l & 15, group
+// g = l >> 4) holds 32 operand bytes; byte j is K index 64 * (j / 16) + 16 * g + (j % 16), and the scale of K block kb
+// (= K / 32) of row r is byte `opsel` of the scale register of lane r + 16 * kb.  So a lane that loads the 16-byte chunk g of
+// the first and of the second 64-byte half of a 128-channel row -- what the bf16 conv kernel's two fragment reads do -- feeds
+// channels 16g.. and 64 + 16g.. in place, the four scale blocks are channels [0,32) [32,64) [64,96) [96,128) of the row, and
+// lane (r, g) supplies the scale of block g.
 // scale byte s: value 2^(s - 127); chosen as 2^(floor(log2(amax)) - 8) (8 = emax of E4M3, OCP MX rule); elements are
 // x / scale rounded to nearest even, saturated at +-448.
 #include "dg_internal.h"
@@ -56,11 +57,11 @@ __global__ void __launch_bounds__(256) quant_mxfp8_kernel(const T* __restrict__ 
   const long long total = rows * nb;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long r = t / nb;
-    const int b = (int)(t - r * nb), grp = b >> 2, g = b & 3;
-    const int c_lo = grp * 128 + 16 * g;
+    const int b = (int)(t - r * nb);
+    const int c_lo = b * 32;
     float v[32];
     QLoad<T>::run(src + r * ld + c_lo, v);
-    QLoad<T>::run(src + r * ld + c_lo + 64, v + 16);
+    QLoad<T>::run(src + r * ld + c_lo + 16, v + 16);
     float amax = 0.f;
 #pragma unroll
     for (int k = 0; k < 32; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[k]));
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(256) quant_mxfp8_kernel(const T* __restrict__ 
     e = e < 0 ? 0 : e;
     const float inv = __uint_as_float((unsigned)(254 - e) << 23);       // 2^(127 - e), exact
     *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo) = pack_fp8x16(v, inv);
-    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo + 64) = pack_fp8x16(v + 16, inv);
+    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo + 16) = pack_fp8x16(v + 16, inv);
     sc[r * nb + b] = (unsigned char)e;
   }
 }

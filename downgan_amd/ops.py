@@ -214,7 +214,7 @@ class HipOps:
     # ------------------------------------------------------------------ MXFP8 conv path
     def quant_mxfp8(self, src, q=None, scales=None):
         """src: [..., C] (bf16 or fp32, unit channel stride, dense rows of stride ld) -> (q uint8 [rows, C], scales uint8
-        [rows, C/32]) in the paired-block MXFP8 layout of csrc/quant.hip."""
+        [rows, C/32]): MXFP8, blocks of 32 consecutive channels (csrc/quant.hip)."""
         Cc = src.shape[-1]
         assert Cc % 128 == 0 and src.stride(-1) == 1 and src.is_cuda
         if src.dim() == 4:

@@ -268,9 +268,8 @@ int dg_gather_samples(int dtype, const void* src, int64_t HW, int c_real, const 
 /* MXFP8 conv path (BASELINE.json configs[4]: "fp8 (CDNA4 fp8 MFMA) conv path"; reference math of the layers it serves:
  * DoWnGAN/networks/critic.py:25-88, the critic's seven 128..1024-channel convs).
  * dg_quant_mxfp8: rows x C values (C % 128 == 0, row stride `ld` elements, dtype DG_BF16 or DG_F32) -> OCP FP8 E4M3 bytes
- *   q[rows][ldq] + one E8M0 scale byte per 32-channel block, scales[rows][C/32].  Block (c / 128) * 4 + g holds channels
- *   128*(c/128) + {16g..16g+15} and + 64 + {16g..16g+15} (the K set one lane group of v_mfma_scale_f32_16x16x128_f8f6f4 reads
- *   in the conv kernel); scale = 2^(floor(log2 amax) - 8), elements = round-to-nearest-even(x / scale) saturated at +-448.
+ *   q[rows][ldq] + one E8M0 scale byte per block of 32 consecutive channels (OCP MX layout), scales[rows][C/32];
+ *   scale = 2^(floor(log2 amax) - 8), elements = round-to-nearest-even(x / scale) saturated at +-448.
  *   Serves activations / adjoints (rows = pixels) and conv weight packs (rows = Nout * 9, C = Cred).
  * dg_conv3x3_fwd_f8 / dg_conv3x3_dgrad_f8: dg_conv3x3_fwd / _dgrad with both MFMA operands in that format and fp32
  *   accumulation; `g` describes the layer as for the bf16 calls (g->dtype = DG_BF16: the type of y / dx and of every

@@ -139,20 +139,20 @@ class EmuOps:
             full[..., :v.shape[-1]] = y[..., :v.shape[-1]].float() > 0
             self._pack_bits(full, out_bits)
 
-    # ---- MXFP8 (csrc/quant.hip): OCP E4M3 elements, one E8M0 scale per "paired" block of 32 channels -- block g of a
-    # 128-channel group = channels {16g + e} and {64 + 16g + e}, e < 16; scale = 2^(floor(log2 amax) - 8)
+    # ---- MXFP8 (csrc/quant.hip): OCP E4M3 elements, one E8M0 scale per block of 32 consecutive channels (OCP MX layout);
+    # scale = 2^(floor(log2 amax) - 8)
     @staticmethod
     def mx_quant(x):
         """x [..., C] -> (q uint8 [rows, C] E4M3 bit patterns, scales uint8 [rows, C/32], dequantised fp32 [..., C])."""
         Cc = x.shape[-1]
         assert Cc % 128 == 0
-        v = x.float().reshape(-1, Cc // 128, 2, 4, 16).permute(0, 1, 3, 2, 4).reshape(-1, Cc // 128, 4, 32)
+        v = x.float().reshape(-1, Cc // 128, 4, 32)
         amax = v.abs().amax(-1)
         e = (((amax.contiguous().view(torch.int32) >> 23) & 0xff) - 8).clamp(min=0)
         scale = torch.ldexp(torch.ones_like(amax), e - 127)
         q8 = (v / scale[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
         deq = q8.float() * scale[..., None]
-        unblock = lambda t: t.reshape(-1, Cc // 128, 4, 2, 16).permute(0, 1, 3, 2, 4).reshape(-1, Cc)
+        unblock = lambda t: t.reshape(-1, Cc)
         return unblock(q8.view(torch.uint8)), e.to(torch.uint8).reshape(-1, Cc // 32), unblock(deq).reshape(x.shape)
 
     def quant_mxfp8(self, src, q=None, scales=None):

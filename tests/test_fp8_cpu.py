@@ -1,4 +1,4 @@
-"""MXFP8 emulation (oracle/emu_ops.py::mx_quant -- the CPU statement of csrc/quant.hip's format): scale rule, paired block
+"""MXFP8 emulation (oracle/emu_ops.py::mx_quant -- the CPU statement of csrc/quant.hip's format): scale rule, block
 layout, saturation and error bound; and the engine's fp8 mode on emulated ops (host plumbing: which layers quantise)."""
 import torch
 
@@ -15,7 +15,7 @@ def test_mx_quant_format():
     for r in range(7):
         for grp in range(2):
             for gg in range(4):
-                idx = [grp * 128 + 16 * gg + e for e in range(16)] + [grp * 128 + 64 + 16 * gg + e for e in range(16)]   # paired block
+                idx = [grp * 128 + 32 * gg + e for e in range(32)]                  # 32 consecutive channels
                 blk = x[r, idx]
                 amax = float(blk.abs().max())
                 e = int(s[r, grp * 4 + gg])
