@@ -69,8 +69,10 @@ static int run(const char* what) {
       const double err = std::fabs(D[r * 16 + c] - ref) / (mag + 1e-30);     // relative to the sum of |products|: cancellation does not count
       if (err > worst) worst = err;
     }
-  printf("%s opsel_a=%d opsel_b=%d: max |D - ref| / sum|a b| %.3e  %s\n", what, OA, OB, worst, worst < 1e-6 ? "OK" : "MISMATCH");
-  return worst < 1e-6 ? 0 : 1;
+  printf("%s opsel_a=%d opsel_b=%d: max |D - ref| / sum|a b| %.3e  %s\n", what, OA, OB, worst, worst < 1e-3 ? "OK (register map)" : "MISMATCH");
+  // (a wrong register / scale map gives errors of order 1..1e3; what remains with the right one, ~1e-4 of sum|a b| on random
+  // bytes that span all 17 binades of E4M3, is the instruction's own accumulation: products are not summed in full fp32)
+  return worst < 1e-3 ? 0 : 1;
 }
 
 int main() {
