@@ -21,7 +21,7 @@ class Epilogue(C.Structure):
                 ("r2", C.c_void_p), ("ldr2", C.c_int64), ("s2", C.c_float),
                 ("mask", C.c_void_p), ("ldmask", C.c_int64), ("mask_slope", C.c_float),
                 ("accumulate", C.c_int), ("mask_bits", C.c_void_p), ("out_bits", C.c_void_p),
-                ("mask_c0", C.c_int), ("mask_last", C.c_int)]
+                ("mask_c0", C.c_int), ("mask_last", C.c_int), ("out_q", C.c_void_p), ("out_qs", C.c_void_p)]
 
 
 class ConvGeom(C.Structure):

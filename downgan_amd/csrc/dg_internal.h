@@ -62,6 +62,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// 16 fp32 values scaled by `inv` (a power of two), saturated at +-448 and rounded to nearest even -> 16 OCP E4M3 bytes
+typedef __attribute__((ext_vector_type(4))) unsigned int dg_u32x4_t;
+__device__ __forceinline__ dg_u32x4_t pack_fp8x16(const float* v, float inv) {
+  dg_u32x4_t o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int w = 0;
+    const float a = __builtin_fminf(__builtin_fmaxf(v[4 * q] * inv, -448.f), 448.f), b = __builtin_fminf(__builtin_fmaxf(v[4 * q + 1] * inv, -448.f), 448.f);
+    const float c = __builtin_fminf(__builtin_fmaxf(v[4 * q + 2] * inv, -448.f), 448.f), d = __builtin_fminf(__builtin_fmaxf(v[4 * q + 3] * inv, -448.f), 448.f);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    o[q] = (unsigned)w;
+  }
+  return o;
+}
+// E8M0 scale byte of an MX block with maximum magnitude amax: 2^(floor(log2 amax) - 8) (8 = emax of E4M3), biased by 127
+__device__ __forceinline__ int mx_scale_byte(float amax) {
+  const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
+  return e < 0 ? 0 : e;
+}
+__device__ __forceinline__ float mx_inv_scale(int e) { return __uint_as_float((unsigned)(254 - e) << 23); }   // 2^(127 - e), exact
+
 static inline int dg_check_launch() { return hipGetLastError() == hipSuccess ? DG_OK : DG_ERR_LAUNCH; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: a launcher that set it once per process would launch

@@ -33,6 +33,7 @@ struct GGArgs {
   const void* x; const void* w; void* y;
   const float* bias; const void* r1; const void* r2; const void* mask;
   const void* mask_bits; void* out_bits;     // 1-bit LeakyReLU masks (u16 per lane: 4 fragments x 4 channels), see dg_epilogue
+  void* out_q; void* out_qs;                 // MXFP8 copy of the stored output (dg_epilogue.out_q / out_qs)
   long long ldx, ldw, ldy, ldr1, ldr2, ldmask;
   int M, Hg, Wg, Hs, Ws;
   int cch, kchunks, Cred, ntaps;
@@ -85,7 +86,7 @@ template <> struct EpiV<float> {
     return t;
   }
 };
-struct EpiRes { __amdgpu_buffer_rsrc_t rY, r1, r2, rm, rbi, rbo; int ldy, ld1, ld2, ldm; };
+struct EpiRes { __amdgpu_buffer_rsrc_t rY, r1, r2, rm, rbi, rbo, rq, rqs; int ldy, ld1, ld2, ldm; };
 template <typename T> struct EpiIO;
 template <> struct EpiIO<bf16_t> {
   typedef u32x2_t V;
@@ -159,6 +160,8 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
   const bool f_mk = F < 0 ? !LEAN && mask_on && !a.mask_last : (F & 32) != 0;       // mask before the accumulate
   const bool f_ml = F < 0 ? !LEAN && mask_on && a.mask_last != 0 : (F & 128) != 0;  // mask after it
   const bool f_ac = F < 0 ? !LEAN && a.accumulate != 0 : (F & 64) != 0;
+  const bool f_q = F < 0 ? a.out_q != nullptr : (F & 256) != 0;                      // MXFP8 copy of the stored values
+  u32x4_t pk[NU];
   // LEAN runs inside a tile loop whose memory operations must be unconditional (see gg_im2col_kernel): absent bit-mask
   // operands become out-of-range offsets (the load returns 0, the store is dropped)
 #pragma unroll
@@ -218,10 +221,30 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
 #pragma unroll
       for (int e = 0; e < CPU; ++e) ob |= (vu[e] > 0.f ? 1u : 0u) << (u * CPU + e);
     }
-    __builtin_amdgcn_raw_buffer_store_b128(IO::pack(vu), R.rY, offy, u * 16, 0);
+    pk[u] = IO::pack(vu);
+    __builtin_amdgcn_raw_buffer_store_b128(pk[u], R.rY, offy, u * 16, 0);
   }
   if (F >= 0) { if (f_ob) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, boff, 0, 0); }
   else if (LEAN || a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, (LEAN && !a.out_bits) ? DG_OOB_OFF : boff, 0, 0);
+  if constexpr (sizeof(T) == 2) {
+    // MXFP8 copy of what was just stored (the bf16-ROUNDED values, so it equals dg_quant_mxfp8 of the stored tensor): the lane
+    // holds 16 consecutive channels, lane ^ 16 the other half of the 32-channel block; one 16-byte store per lane, the scale byte
+    // from the lane with the lower half.  q has y's pixel stride (in bytes = elements), scales [pixel][Nout / 32]:
+    // byte offsets offy / 2 and boff / 4 ((rel * Nout + channel) / 32).
+    if (f_q) {
+      float w[16];
+      IO::unpack(pk[0], w); IO::unpack(pk[1], w + 8);
+      float amax = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(w[k]));
+      amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
+      const int e = mx_scale_byte(amax);
+      const u32x4_t qv = __builtin_bit_cast(u32x4_t, pack_fp8x16(w, mx_inv_scale(e)));
+      __builtin_amdgcn_raw_buffer_store_b128(qv, R.rq, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
+      const bool low_half = ((threadIdx.x >> 4) & 1) == 0;
+      __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, R.rqs, (low_half && boff != DG_OOB_OFF) ? boff >> 2 : DG_OOB_OFF, 0, 0);
+    }
+  }
 }
 
 // ---- Epilogue of the row-tiled kernels (generic / fast / im2col): like halo_epilogue below, every tensor is
@@ -264,6 +287,7 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
     R.rY = rsrc(a.y, a.ldy, ES);
     R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
     R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
+    R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.Nout >> 5, 1);
     R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
     int relv[FP];
     bool okv[FP];
@@ -677,6 +701,7 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
   R.rY = rsrc(a.y, a.ldy, ES);
   R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
   R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
+  R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.Nout >> 5, 1);
   R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
   const bool xok = tx0 + l15 < a.Wg;
   // every mask word of the wave's tile first (NH halves x 4 rows), before the first store
@@ -720,7 +745,8 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
   };
   // the flag combinations the train step launches most get straight-line instances; everything else the general one.
   // Decoded per 64-channel half: the activation mask may start at channel mask_c0 (a multiple of 64 here, else general path)
-  const int key0 = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.r1 ? 8 : 0) | (a.r2 ? 16 : 0) | (a.accumulate ? 64 : 0);
+  const int key0 = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.r1 ? 8 : 0) | (a.r2 ? 16 : 0) | (a.accumulate ? 64 : 0) |
+                   (a.out_q ? 256 : 0);
   auto dispatch = [&](auto htag) {
     constexpr int h = decltype(htag)::value;
     int key = key0;
@@ -736,6 +762,8 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       case 64: run(std::integral_constant<int, 64>{}, htag); break;    // accumulate (dense-block data gradients)
       case 128: run(std::integral_constant<int, 128>{}, htag); break;  // mask of the completed top slice (dense block, conv 5's data gradient)
       case 192: run(std::integral_constant<int, 192>{}, htag); break;  // accumulate, then the completed slice's mask (convs 4..2)
+      case 258: run(std::integral_constant<int, 258>{}, htag); break;  // fp8 mode: 1-bit mask + MXFP8 copy (critic data gradients, tangent forward)
+      case 261: run(std::integral_constant<int, 261>{}, htag); break;  // fp8 mode: LeakyReLU + out_bits + MXFP8 copy (critic forward)
       default: run(std::integral_constant<int, -1>{}, htag); break;
     }
   };
@@ -1865,6 +1893,7 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void gg_im2col_kernel(const GGAr
     R.rY = rsrc(a.y, a.ldy, ES);
     R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
     R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
+    R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.Nout >> 5, 1);
     R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
     unsigned mbv[4];
 #pragma unroll
@@ -2061,6 +2090,10 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     if (a.mask_c0 < 0 || a.mask_c0 % 16 || ((a.mask_c0 || a.mask_last) && !a.mask)) return DG_ERR_BAD_ARG;
     a.accumulate = ep->accumulate;
     a.mask_bits = ep->mask_bits; a.out_bits = ep->out_bits;
+    a.out_q = ep->out_q; a.out_qs = ep->out_qs;
+    // the MXFP8 copy is written by the 64-channel wave-tile epilogues of bf16 launches: same shape rules as the bit masks
+    if ((a.out_q != nullptr) != (a.out_qs != nullptr)) return DG_ERR_BAD_ARG;
+    if (a.out_q && (d->dtype != DG_BF16 || d->Nout < 128 || d->Nout % 64 || d->dst_ps)) return DG_ERR_BAD_SHAPE;
     // bit masks need 64-channel wave tiles (Nout >= 128 selects them in every dispatch path) and plain destinations
     if ((a.mask_bits || a.out_bits) && (d->Nout < 128 || d->Nout % 64 || d->dst_ps || (a.mask_bits && a.mask))) return DG_ERR_BAD_SHAPE;
     if ((a.r1 && a.ldr1 % 4) || (a.r2 && a.ldr2 % 4) || (a.mask && a.ldmask % 4)) return DG_ERR_BAD_SHAPE;

@@ -35,20 +35,6 @@ template <> struct QLoad<float> {
   }
 };
 
-__device__ __forceinline__ q_u32x4_t pack_fp8x16(const float* v, float inv) {
-  q_u32x4_t o;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    int w = 0;
-    const float a = __builtin_fminf(__builtin_fmaxf(v[4 * q] * inv, -448.f), 448.f), b = __builtin_fminf(__builtin_fmaxf(v[4 * q + 1] * inv, -448.f), 448.f);
-    const float c = __builtin_fminf(__builtin_fmaxf(v[4 * q + 2] * inv, -448.f), 448.f), d = __builtin_fminf(__builtin_fmaxf(v[4 * q + 3] * inv, -448.f), 448.f);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    o[q] = (unsigned)w;
-  }
-  return o;
-}
-
 // one thread = one block of one row: rows x (C / 32) threads
 template <typename T>
 __global__ void __launch_bounds__(256) quant_mxfp8_kernel(const T* __restrict__ src, long long rows, long long ld, int C,
@@ -65,9 +51,8 @@ __global__ void __launch_bounds__(256) quant_mxfp8_kernel(const T* __restrict__ 
     float amax = 0.f;
 #pragma unroll
     for (int k = 0; k < 32; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[k]));
-    int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;          // biased exponent of 2^(floor(log2 amax) - 8)
-    e = e < 0 ? 0 : e;
-    const float inv = __uint_as_float((unsigned)(254 - e) << 23);       // 2^(127 - e), exact
+    const int e = mx_scale_byte(amax);
+    const float inv = mx_inv_scale(e);
     *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo) = pack_fp8x16(v, inv);
     *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo + 16) = pack_fp8x16(v + 16, inv);
     sc[r * nb + b] = (unsigned char)e;

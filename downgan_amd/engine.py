@@ -59,6 +59,7 @@ class ParamStore:
         self.entries = {}      # name -> (offset, numel, shape)
         self.size = 0
         self.conv_dgrad = {}   # name -> (cout_p, cin_p)
+        self.after_refresh = []   # callbacks run whenever the compute-precision packs were re-derived (fp8 weight forms)
 
     def add(self, name, shape):
         n = int(math.prod(shape))
@@ -124,6 +125,8 @@ class ParamStore:
             o.cast(self.p, self.shadow)
         for name, (co, ci) in self.conv_dgrad.items():
             o.repack(self.master(name).reshape(-1), self.dgrad_pack[name], co, ci, 1)
+        for fn in self.after_refresh:
+            fn()
 
     def zero_grad(self):
         self.sync()
@@ -201,6 +204,35 @@ class NativeCritic:
         self.dout = o.zeros(batch, FC_OUT_P, dtype=torch.float32)
         self.uh1 = o.zeros(batch, FC_HID_LD, dtype=torch.float32)
         self._tan = None
+        # fp8 mode (BASELINE configs[4]): MXFP8 forms of every tensor an fp8 conv reads -- activations act[l-1] (forward of
+        # layer l), adjoints us[l] (data gradient of layer l), the penalty's tangents, both weight packs -- written by the
+        # PRODUCING launch's epilogue (dg_epilogue.out_q) or, for the weights, once per optimizer step; None = not needed
+        self.f8 = bool(getattr(o, "f8", False))
+        qbuf = lambda t: (o.zeros(t.numel(), dtype=torch.uint8), o.zeros(t.numel() // 32, dtype=torch.uint8))
+        self.actq = [None] * 8
+        self.usq = [None] * 8
+        self.wq_f, self.wq_d = [None] * 8, [None] * 8
+        self._tanq = None
+        if self.f8:
+            for l, cv in enumerate(self.convs):
+                if l + 1 < 8 and o.f8_eligible(self.convs[l + 1], "fwd"):
+                    self.actq[l] = qbuf(self.acts[l])
+                if o.f8_eligible(cv, "dgrad"):
+                    self.usq[l] = qbuf(self.us[l])
+                    self.wq_d[l] = (o.zeros(cv.Cout * 9 * cv.Cin, dtype=torch.uint8), o.zeros(cv.Cout * 9 * cv.Cin // 32, dtype=torch.uint8))
+                if o.f8_eligible(cv, "fwd"):
+                    self.wq_f[l] = (o.zeros(cv.Cout * 9 * cv.Cin, dtype=torch.uint8), o.zeros(cv.Cout * 9 * cv.Cin // 32, dtype=torch.uint8))
+            P.after_refresh.append(self._requantise_weights)
+
+    def _requantise_weights(self):
+        o, P = self.ops, self.P
+        for l, cv in enumerate(self.convs):
+            name = f"features.{2 * l}.weight"
+            off, n, _ = P.entries[name]
+            if self.wq_f[l] is not None:
+                o.quant_mxfp8(P.shadow[off:off + n].view(cv.Cout * 9, cv.Cin), *self.wq_f[l])
+            if self.wq_d[l] is not None:
+                o.quant_mxfp8(P.dgrad_pack[name].view(cv.Cin * 9, cv.Cout), *self.wq_d[l])
 
     # ---- state_dict interchange (reference key names / OIHW) -------------------------------------
     def load_state_dict(self, sd):
@@ -243,9 +275,10 @@ class NativeCritic:
         o, P = self.ops, self.P
         cur = x
         for l, cv in enumerate(self.convs):
+            f8kw = dict(xq=self.actq[l - 1] if l else None, wq=self.wq_f[l], out_q=self.actq[l]) if self.f8 else {}
             o.conv_fwd(cv, cur, P.w(f"features.{2 * l}.weight"), self.acts[l],
                        bias=P.master("features.0.bias") if l == 0 else None, act=C_SLOPE,
-                       out_bits=self.act_bits[l] if self.act_bits else None)
+                       out_bits=self.act_bits[l] if self.act_bits else None, **f8kw)
             cur = self.acts[l]
         y7 = self.acts[7].view(self.B, self.fc_k)
         self.h1pre.zero_()
@@ -274,6 +307,8 @@ class NativeCritic:
             o.colsum(self.uh1, P.grad("classifier.0.bias"))
         o.linear_dx(self.uh1[:, :FC_HID_P], P.w2d("classifier.0.weight"), self.us[7].view(self.B, self.fc_k),
                     mask=y7, mask_slope=C_SLOPE, o_real=FC_HID, net="C")
+        if self.usq[7] is not None:       # the only adjoint that does not come out of a conv epilogue
+            o.quant_mxfp8(self.us[7], *self.usq[7])
         for l in range(7, -1, -1):
             cv = self.convs[l]
             name = f"features.{2 * l}.weight"
@@ -281,10 +316,11 @@ class NativeCritic:
             if wgrad:   # features.0 also carries the only conv bias of the critic (critic.py:21-23)
                 o.conv_wgrad(cv, xin, self.us[l], P.grad(name).reshape(-1), db=P.grad("features.0.bias") if l == 0 else None)
             if l > 0:
+                f8kw = dict(xq=self.usq[l], wq=self.wq_d[l], out_q=self.usq[l - 1]) if self.f8 else {}
                 if self.act_bits:
-                    o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask_bits=self.act_bits[l - 1], mask_slope=C_SLOPE)
+                    o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask_bits=self.act_bits[l - 1], mask_slope=C_SLOPE, **f8kw)
                 else:
-                    o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask=self.acts[l - 1], mask_slope=C_SLOPE)
+                    o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask=self.acts[l - 1], mask_slope=C_SLOPE, **f8kw)
             elif dx is not None:
                 o.conv_dgrad(cv, self.us[0], P.wd(name), dx)
 
@@ -309,16 +345,24 @@ class NativeCritic:
             self._th1 = o.zeros(self.B, FC_HID_LD)
             self._ones = o.zeros(self.B, FC_OUT_P, dtype=torch.float32)
             o.fill_col(self._ones, 0, 1.0)
-        t = v_buf
+            if self.f8:
+                self._tanq = [(o.zeros(big, dtype=torch.uint8), o.zeros(big // 32, dtype=torch.uint8)) for _ in range(2)]
+        t, tq = v_buf, None
         for l, cv in enumerate(self.convs):
             name = f"features.{2 * l}.weight"
             o.conv_wgrad(cv, t, self.us[l], P.grad(name).reshape(-1))
             tn = self._tan[l & 1][:self.acts[l].numel()].view(self.acts[l].shape)
+            f8kw, tqn = {}, None
+            if self.f8:
+                if self.actq[l] is not None:          # the next layer's tangent forward is an fp8 conv
+                    n = self.acts[l].numel()
+                    tqn = (self._tanq[l & 1][0][:n], self._tanq[l & 1][1][:n // 32])
+                f8kw = dict(xq=tq, wq=self.wq_f[l], out_q=tqn)
             if self.act_bits:
-                o.conv_fwd(cv, t, P.w(name), tn, mask_bits=self.act_bits[l], mask_slope=C_SLOPE)
+                o.conv_fwd(cv, t, P.w(name), tn, mask_bits=self.act_bits[l], mask_slope=C_SLOPE, **f8kw)
             else:
-                o.conv_fwd(cv, t, P.w(name), tn, mask=self.acts[l], mask_slope=C_SLOPE)
-            t = tn
+                o.conv_fwd(cv, t, P.w(name), tn, mask=self.acts[l], mask_slope=C_SLOPE, **f8kw)
+            t, tq = tn, tqn
         t7 = t.view(self.B, self.fc_k)
         o.linear_dw(self.uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
         self._th1pre.zero_()

@@ -146,7 +146,7 @@ class HipOps:
         return (N, H, W, Cc // 64, 4)
 
     def _epilogue(self, out, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None, mask_slope=1.0,
-                  accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False):
+                  accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None):
         ep = Epilogue()
         ep.bias = bias.data_ptr() if bias is not None else None
         if bias is not None:
@@ -175,6 +175,12 @@ class HipOps:
                 assert t.dtype == torch.int16 and t.is_cuda and t.is_contiguous() and tuple(t.shape) == self.bits_shape(out.shape), (name, t.shape, out.shape)
                 setattr(ep, name, t.data_ptr())
         assert not (mask is not None and mask_bits is not None)
+        if out_q is not None:       # (q, scales): MXFP8 copy of the stored output, q with `out`'s pixel stride
+            q, qs = out_q
+            Cc = out.shape[-1]
+            assert out.dtype == torch.bfloat16 and out.is_contiguous() and Cc % 64 == 0 and Cc >= 128
+            assert q.dtype == torch.uint8 and qs.dtype == torch.uint8 and q.numel() == out.numel() and qs.numel() == out.numel() // 32
+            ep.out_q, ep.out_qs = q.data_ptr(), qs.data_ptr()
         return ep
 
     # ------------------------------------------------------------------ conv family
@@ -183,29 +189,37 @@ class HipOps:
             return (cv.N, 2 * cv.Ho, 2 * cv.Wo, cv.Cout // 4)
         return (cv.N, cv.Ho, cv.Wo, cv.Cout)
 
-    def conv_fwd(self, cv: Conv, x, w_fwd, y, **ep):
+    def f8_eligible(self, cv: Conv, kind):
+        """Does this layer's forward ("fwd") / data gradient ("dgrad") run on the MXFP8 kernel in f8 mode?"""
+        cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
+        return self.f8 and cv.net == "C" and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
+
+    def conv_fwd(self, cv: Conv, x, w_fwd, y, xq=None, wq=None, **ep):
+        """``xq`` / ``wq`` (f8 mode, optional): (q, scales) MXFP8 forms of ``x`` / ``w_fwd`` that a producer already wrote
+        (``out_q=`` of the previous layer's launch, ``quant_mxfp8`` of the weight pack after an optimizer step); without them
+        the operands are quantised on the fly."""
         self._act(x); self._act(y); self._act(w_fwd)
         assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin), (x.shape, cv)
         assert tuple(y.shape) == self.out_shape(cv), (y.shape, cv)
         assert w_fwd.numel() == cv.Cout * 9 * cv.Cin and w_fwd.is_contiguous()
         g = self._geom(cv, pix_layout(x)[0], pix_layout(y)[0])
         e = self._epilogue(y, **ep)
-        if self.f8 and cv.net == "C" and cv.Cin % 128 == 0 and cv.Cout > 64 and not cv.pixel_shuffle:
-            check(self._timed("conv_fwd", self.conv_flops(cv), lambda: self._conv_f8(self.lib.dg_conv3x3_fwd_f8, g, e, x, w_fwd, cv.Cout, cv.Cin, y),
+        if self.f8_eligible(cv, "fwd"):
+            check(self._timed("conv_fwd", self.conv_flops(cv), lambda: self._conv_f8(self.lib.dg_conv3x3_fwd_f8, g, e, x, w_fwd, cv.Cout, cv.Cin, y, xq, wq),
                               self.conv_bytes(cv, ep), cv.net, self._geom_tag(cv)), "dg_conv3x3_fwd_f8")
             return
         check(self._timed("conv_fwd", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_fwd(
             C.byref(g), C.byref(e), _ptr(x), _ptr(w_fwd), _ptr(y), self._stream()), self.conv_bytes(cv, ep), cv.net, self._geom_tag(cv)), "dg_conv3x3_fwd")
 
-    def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, **ep):
+    def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, xq=None, wq=None, **ep):
         self._act(dy); self._act(dx); self._act(w_dgrad)
         assert tuple(dx.shape) == (cv.N, cv.H, cv.W, cv.Cin), (dx.shape, cv)
         assert tuple(dy.shape) == self.out_shape(cv), (dy.shape, cv)
         assert w_dgrad.numel() == cv.Cout * 9 * cv.Cin and w_dgrad.is_contiguous()
         g = self._geom(cv, pix_layout(dx)[0], pix_layout(dy)[0])
         e = self._epilogue(dx, **ep)
-        if self.f8 and cv.net == "C" and cv.Cout % 128 == 0 and cv.Cin > 64 and not cv.pixel_shuffle:
-            check(self._timed("conv_dgrad", self.conv_flops(cv), lambda: self._conv_f8(self.lib.dg_conv3x3_dgrad_f8, g, e, dy, w_dgrad, cv.Cin, cv.Cout, dx),
+        if self.f8_eligible(cv, "dgrad"):
+            check(self._timed("conv_dgrad", self.conv_flops(cv), lambda: self._conv_f8(self.lib.dg_conv3x3_dgrad_f8, g, e, dy, w_dgrad, cv.Cin, cv.Cout, dx, xq, wq),
                               self.conv_bytes(cv, ep), cv.net, self._geom_tag(cv)), "dg_conv3x3_dgrad_f8")
             return
         check(self._timed("conv_dgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_dgrad(
@@ -238,12 +252,16 @@ class HipOps:
             b = self._f8_scratch[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
         return b
 
-    def _conv_f8(self, fn, g, e, src, w, nout, cred, dst):
-        """quantise the bf16 source tensor and weight pack into scratch, then the fp8 conv (forward or data gradient)."""
+    def _conv_f8(self, fn, g, e, src, w, nout, cred, dst, xq=None, wq=None):
+        """the fp8 conv (forward or data gradient); operands that come without an MXFP8 form are quantised into scratch."""
         rows = src.numel() // cred
-        xq, xs = self.quant_mxfp8(src, self._f8_buf("xq", rows * cred), self._f8_buf("xs", rows * (cred // 32)))
-        wv = w.view(nout * 9, cred)
-        wq, ws = self.quant_mxfp8(wv, self._f8_buf("wq", wv.numel()), self._f8_buf("ws", wv.numel() // 32))
+        if xq is None:
+            xq = self.quant_mxfp8(src, self._f8_buf("xq", rows * cred), self._f8_buf("xs", rows * (cred // 32)))
+        if wq is None:
+            wv = w.view(nout * 9, cred)
+            wq = self.quant_mxfp8(wv, self._f8_buf("wq", wv.numel()), self._f8_buf("ws", wv.numel() // 32))
+        (xq, xs), (wq, ws) = xq, wq
+        assert xq.numel() >= rows * cred and xs.numel() >= rows * (cred // 32) and wq.numel() >= nout * 9 * cred
         q = _lib.F8Operands(xq=xq.data_ptr(), xs=xs.data_ptr(), ldxq=cred, wq=wq.data_ptr(), ws=ws.data_ptr())
         return fn(C.byref(g), C.byref(e), C.byref(q), _ptr(dst), self._stream())
 

@@ -66,6 +66,12 @@ typedef struct dg_epilogue {
   void* out_bits;
   int mask_c0;
   int mask_last;
+  /* MXFP8 copy of the stored output for the fp8 conv path (see dg_quant_mxfp8 below): out_q [pixel][ld of y] E4M3 bytes
+   * (same pixel stride as y, counted in bytes) and out_qs [pixel][Cout/32] E8M0 scale bytes, bit-identical to
+   * dg_quant_mxfp8 of the bf16 tensor this launch stores -- the next layer's fp8 conv reads them instead of a separate
+   * quantisation pass.  Both or neither; bf16 launches with Cout % 64 == 0, Cout >= 128, no pixel shuffle. */
+  void* out_q;
+  void* out_qs;
 } dg_epilogue;
 
 /* Geometry of ONE reference nn.Conv2d(Cin, Cout, kernel_size=3, stride, padding=1) layer

@@ -76,7 +76,7 @@ class EmuOps:
         return torch.stack([(w[..., blk[c], g[c]] >> int(b[c])) & 1 for c in range(Cc)], dim=-1).bool()
 
     def _gather_gemm(self, d, x, w, y, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None,
-                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False):
+                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None):
         N = d.N
         xs = x.float()
         if d.src_ps:
@@ -138,6 +138,10 @@ class EmuOps:
             full = torch.zeros(*y.shape, dtype=torch.bool)
             full[..., :v.shape[-1]] = y[..., :v.shape[-1]].float() > 0
             self._pack_bits(full, out_bits)
+        if out_q is not None:      # MXFP8 copy of the stored (rounded) output; a strided destination is complete after its last class
+            q, s, _ = self.mx_quant(y)
+            out_q[0].view(-1)[:q.numel()].copy_(q.reshape(-1))
+            out_q[1].view(-1)[:s.numel()].copy_(s.reshape(-1))
 
     # ---- MXFP8 (csrc/quant.hip): OCP E4M3 elements, one E8M0 scale per block of 32 consecutive channels (OCP MX layout);
     # scale = 2^(floor(log2 amax) - 8)
@@ -157,22 +161,44 @@ class EmuOps:
 
     def quant_mxfp8(self, src, q=None, scales=None):
         qq, ss, _ = self.mx_quant(src)
-        return qq, ss
+        if q is None:
+            return qq, ss
+        q.view(-1)[:qq.numel()].copy_(qq.reshape(-1))
+        scales.view(-1)[:ss.numel()].copy_(ss.reshape(-1))
+        return q, scales
 
-    def _f8_eligible(self, cv, cred, nout):
+    def f8_eligible(self, cv, kind):
+        cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
         return self.f8 and cv.net == "C" and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
 
-    def conv_fwd(self, cv: Conv, x, w_fwd, y, **ep):
+    @staticmethod
+    def mx_dequant(q, s, shape):
+        """(E4M3 bytes, E8M0 scale bytes) -> fp32 values of `shape`."""
+        Cc = shape[-1]
+        v = q.reshape(-1, Cc // 32, 32).view(torch.float8_e4m3fn).float()
+        sc = torch.ldexp(torch.ones(s.numel()), s.reshape(-1).int() - 127).reshape(-1, Cc // 32, 1)
+        return (v * sc).reshape(shape)
+
+    def _f8_operand(self, t, pre, rows, cred):
+        """dequantised fp32 value of an operand: from its producer-written MXFP8 form if given, else quantised here."""
+        if pre is not None:
+            q, s = pre
+            return self.mx_dequant(q.reshape(-1)[:rows * cred], s.reshape(-1)[:rows * (cred // 32)], (rows, cred))
+        return self.mx_quant(t.reshape(rows, cred))[2]
+
+    def conv_fwd(self, cv: Conv, x, w_fwd, y, xq=None, wq=None, **ep):
         assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(y.shape) == self.out_shape(cv)
         (d,) = self._plan(cv, 0, pix_layout(x)[0], pix_layout(y)[0])
-        if self._f8_eligible(cv, cv.Cin, cv.Cout):       # fp8 operands, exact products, fp32 accumulation
-            x, w_fwd = self.mx_quant(x)[2], self.mx_quant(w_fwd.view(cv.Cout * 9, cv.Cin))[2]
+        if self.f8_eligible(cv, "fwd"):       # fp8 operands, exact products, fp32 accumulation
+            x = self._f8_operand(x, xq, x.numel() // cv.Cin, cv.Cin).reshape(x.shape)
+            w_fwd = self._f8_operand(w_fwd, wq, cv.Cout * 9, cv.Cin)
         self._gather_gemm(d, x, w_fwd, y, **ep)
 
-    def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, **ep):
+    def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, xq=None, wq=None, **ep):
         assert tuple(dx.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(dy.shape) == self.out_shape(cv)
-        if self._f8_eligible(cv, cv.Cout, cv.Cin):
-            dy, w_dgrad = self.mx_quant(dy)[2], self.mx_quant(w_dgrad.view(cv.Cin * 9, cv.Cout))[2]
+        if self.f8_eligible(cv, "dgrad"):
+            dy = self._f8_operand(dy, xq, dy.numel() // cv.Cout, cv.Cout).reshape(dy.shape)
+            w_dgrad = self._f8_operand(w_dgrad, wq, cv.Cin * 9, cv.Cout)
         for d in self._plan(cv, 1, pix_layout(dx)[0], pix_layout(dy)[0]):
             self._gather_gemm(d, dy, w_dgrad, dx, **ep)
 

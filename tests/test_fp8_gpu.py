@@ -119,3 +119,49 @@ def test_fp8_engine_iteration_matches_emulated_engine():
     for k in ("c_real_mean", "c_fake_mean", "gp_ret", "critic_loss", "g_loss", "content_loss"):
         a, b = res["hip"][k], res["emu"][k]
         assert abs(a - b) <= 2e-2 * max(abs(b), 0.05), (k, a, b)
+
+
+@pytest.mark.parametrize("case", ["halo_bf16", "im2col_first_layer", "fp8_producer", "s2_dgrad_classes", "general_epilogue"])
+def test_fused_mxfp8_output_equals_quantised_store(case):
+    """dg_epilogue.out_q / out_qs: the MXFP8 copy a conv epilogue writes beside its bf16 output is bit-identical to
+    dg_quant_mxfp8 of that output (so the consumer's results do not depend on who quantised)."""
+    g = torch.Generator().manual_seed(31)
+    f8 = case == "fp8_producer"
+    hip = HipOps("bf16", f8_critic=True)
+    if case == "im2col_first_layer":          # critic features.0: 2 real input channels, 128 outputs (critic.py:21-24)
+        cv = Conv(2, 48, 80, 16, 128, 1, False, cin_real=2, net="C")
+    elif case == "s2_dgrad_classes":
+        cv = Conv(1, 64, 96, 128, 256, 2, False, net="C")
+    else:
+        cv = Conv(2, 40, 56, 128, 256, 1, False, net="C" if f8 else "")
+    def qpair(shape):
+        n = 1
+        for d in shape:
+            n *= d
+        return torch.zeros(n, dtype=torch.uint8).cuda(), torch.zeros(n // 32, dtype=torch.uint8).cuda()
+    if case == "s2_dgrad_classes":
+        dy = (torch.randn(hip.out_shape(cv), generator=g) * 1e-3).to(torch.bfloat16).cuda()
+        wd = (torch.randn(cv.Cout * 9 * cv.Cin, generator=g) * 0.05).to(torch.bfloat16).cuda()
+        mb = torch.randint(0, 1 << 15, hip.bits_shape((cv.N, cv.H, cv.W, cv.Cin)), generator=g).to(torch.int16).cuda()
+        y = torch.zeros(cv.N, cv.H, cv.W, cv.Cin, dtype=torch.bfloat16).cuda()
+        oq = qpair(y.shape)
+        hip.conv_dgrad(cv, dy, wd, y, mask_bits=mb, mask_slope=0.2, out_q=oq)
+    else:
+        x = torch.randn(cv.N, cv.H, cv.W, cv.Cin, generator=g).to(torch.bfloat16)
+        if cv.cin_real:
+            x[..., cv.cin_real:] = 0
+        w = (torch.randn(cv.Cout * 9 * cv.Cin, generator=g) * 0.05).to(torch.bfloat16).cuda()
+        y = torch.zeros(hip.out_shape(cv), dtype=torch.bfloat16).cuda()
+        oq = qpair(y.shape)
+        ob = torch.zeros(hip.bits_shape(y.shape), dtype=torch.int16).cuda()
+        if case == "general_epilogue":     # residual + activation: not one of the straight-line epilogue instances
+            r1 = torch.randn(y.shape, generator=g).to(torch.bfloat16).cuda()
+            hip.conv_fwd(cv, x.cuda(), w, y, act=0.2, r1=r1, s1=0.5, out_q=oq)
+        else:
+            b = torch.randn(cv.Cout, generator=g).cuda() if cv.cin_real else None
+            hip.conv_fwd(cv, x.cuda(), w, y, bias=b, act=0.2, out_bits=ob, out_q=oq)
+            assert hip.lib.dg_last_conv_kernels() == (32 if f8 else 16 if cv.cin_real else 8)
+    q_ref, s_ref = hip.quant_mxfp8(y)
+    assert float(y.float().abs().max()) > 0
+    assert torch.equal(oq[1].view_as(s_ref), s_ref), int((oq[1].view_as(s_ref) != s_ref).sum())
+    assert torch.equal(oq[0].view_as(q_ref), q_ref), int((oq[0].view_as(q_ref) != q_ref).sum())
