@@ -1114,16 +1114,21 @@ static bool regroup_taps_by_plane(GGArgs& a) {
 // pairs with 1 / 2 / 2 / 4 taps, the plane's patch gathered with stride 2.
 // PS: pixel-shuffled source (data gradient of an up-sampling conv): virtual pixel (y, x), channel quarter q = stored pixel
 // (2y + (q >> 1), 2x + (q & 1)); a 64-channel block lies inside one quarter, so its patch is a stride-2 gather like S2's.
-template <typename T, bool S2, bool PS = false>
-__global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+// NW = 8: the same kernel with EIGHT waves and a 16x16-pixel x 256-channel tile (waves 0-3 the first 128 channels, waves 4-7
+// the second), one workgroup per CU.  Both channel halves read ONE patch, so the patch bytes per flop halve -- which is what
+// bounds the stride-2 forward (a stride-2 tile reads 4x the input pixels of a stride-1 tile: 227 flop per patch byte at 128
+// channels, and the per-CU global->LDS path sustains only ~10-12 B/clk) -- at the price of the second, independent workgroup.
+template <typename T, bool S2, bool PS = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+  constexpr int NT = 64 * NW, RPP = NT / 8;                              // threads; patch rows staged per pass
   constexpr int EPC = DT<T>::EPC;
   constexpr int ES = (int)sizeof(T);
   constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
-  constexpr int BC = 128, KC = 8;                                        // 8 chunks per row: 64 bf16 / 32 fp32 channels
+  constexpr int BC = 32 * NW, KC = 8;                                    // 8 chunks per row: 64 bf16 / 32 fp32 channels
   constexpr int PITCH = KC * 16 + 16;                                    // 144 B patch rows
   constexpr int WROW = KC * 16;                                          // 128 B weight rows, chunk c of row r at c ^ ((r >> 1) & 7)
-  constexpr int NPL = (PROWS * KC + 255) / 256;                          // 11 patch chunks per thread
-  constexpr int NWL = BC * KC / 256;                                     // 4 weight pieces per wave and step
+  constexpr int NPL = (PROWS * KC + NT - 1) / NT;                        // 11 (6) patch chunks per thread
+  constexpr int NWL = BC * KC / NT;                                      // 4 weight pieces per wave and step
   extern __shared__ __attribute__((aligned(16))) char dsm4w[];
   char* const s_patch = dsm4w;                    // [PROWS][PITCH]
   char* const s_w = dsm4w + PROWS * PITCH;        // [2][BC][WROW]
@@ -1136,7 +1141,8 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   const int ty0 = (rest % tiles_y) * TH;
   const int img = rest / tiles_y;
   const int c0 = tile_c * BC;
-  const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0,32)
+  const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0, RPP)
+  const int wq = wave & 3, wh = wave >> 2;        // tile rows 4*wq.., channel half wh (0 unless NW = 8)
   const int sy_base = S2 ? (ty0 > 0 ? 2 * (ty0 - 1) : 0) : (ty0 - 1 > 0 ? ty0 - 1 : 0);
   const char* Xb = PS ? reinterpret_cast<const char*>(a.x) + ((long long)img * 2 * a.Hs + 2 * sy_base) * (2 * a.Ws) * a.ldx * ES
                       : reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
@@ -1173,7 +1179,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     asm volatile("" : "+v"(r0v));
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      const int pr = r0v + 32 * i;
+      const int pr = r0v + RPP * i;
       const int py = pr / PW, px = pr - py * PW;
       const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
       const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
@@ -1188,8 +1194,8 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      const int pr = r0 + 32 * i;
-      if (pr < PROWS) *reinterpret_cast<uint4*>(st_base + i * 32 * PITCH) = __builtin_bit_cast(uint4, rp[i]);
+      const int pr = r0 + RPP * i;
+      if (pr < PROWS) *reinterpret_cast<uint4*>(st_base + i * RPP * PITCH) = __builtin_bit_cast(uint4, rp[i]);
     }
   };
   typedef int i32x4h_t __attribute__((ext_vector_type(4)));
@@ -1216,7 +1222,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
     for (int i = 0; i < NWL; ++i) dma_piece(i);
   };
   auto barrier_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
-  auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); __syncthreads(); };
+  auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPL) : "memory"); __syncthreads(); };
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -1226,7 +1232,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
 
   const char* fa_k[2];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) fa_k[kk] = s_w + l15 * WROW + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) * 16);
+  for (int kk = 0; kk < 2; ++kk) fa_k[kk] = s_w + (wh * 128 + l15) * WROW + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) * 16);
   const char* const fb_lane = s_patch + l15 * PITCH + g * 16;
   auto read_frags = [&](uint4 (&fa)[8], uint4 (&fb)[4], int pa, const char* pb, int kk) {
 #pragma unroll
@@ -1244,7 +1250,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   auto patch_ptr = [&](int vcb_, int tap_) -> const char* {
     const unsigned code = tap_code(vcb_, tap_);
     const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
-    return fb_lane + ((wave * 4 + 1 + dy) * PW + 1 + dx) * PITCH;
+    return fb_lane + ((wq * 4 + 1 + dy) * PW + 1 + dx) * PITCH;
   };
 
 #ifdef DG_STAMP
@@ -1317,7 +1323,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
   unsigned long long tL1, tX;
   STAMP(tL1);
 #endif
-  halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0, wave, 0, l15, g);
+  halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
 #ifdef DG_STAMP
   STAMP(tX);
   if (blockIdx.x < 2 && lane == 0) {
@@ -1327,15 +1333,16 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_kernel(const GGArgs a, int t
 #endif
 }
 
-template <typename T, bool S2, bool PS = false>
+template <typename T, bool S2, bool PS = false, int NW = 4>
 static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
-  constexpr int LDS_BYTES = 324 * 144 + 2 * 128 * 128;
-  DG_SET_MAX_LDS_ONCE((&gg_halo4w_kernel<T, S2, PS>), LDS_BYTES);
+  constexpr int BC = 32 * NW;
+  constexpr int LDS_BYTES = 324 * 144 + 2 * BC * 128;
+  DG_SET_MAX_LDS_ONCE((&gg_halo4w_kernel<T, S2, PS, NW>), LDS_BYTES);
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
-  a.nct = (unsigned)((a.Nout + 127) / 128);
+  a.nct = (unsigned)((a.Nout + BC - 1) / BC);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
   g_last_kinds |= 8;
-  hipLaunchKernelGGL((gg_halo4w_kernel<T, S2, PS>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL((gg_halo4w_kernel<T, S2, PS, NW>), dim3(a.nwg), dim3(64 * NW), LDS_BYTES, st, a, tiles_x, tiles_y);
   return dg_check_launch();
 }
 
@@ -2032,6 +2039,11 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
     GGArgs b = a;
     if (regroup_taps_by_plane(b)) {
       static const bool no4w_s2 = getenv("DG_GG_NO4W") != nullptr || getenv("DG_GG_NO4WS2") != nullptr;
+      // >= 256 output channels (bf16): eight waves share one parity-plane patch between two 128-channel halves
+      static const bool no8w = getenv("DG_GG_NO8W") != nullptr;
+      if constexpr (sizeof(T) == 2) {
+        if (!no4w_s2 && !no8w && b.Nout % 256 == 0) return gg_launch_halo4w<T, true, false, 8>(b, N, st);
+      }
       if (!no4w_s2) return gg_launch_halo4w<T, true>(b, N, st);
       return gg_launch_halo128<T, 1>(b, N, st);
     }
