@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}   # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0, "fp8c": 5000.0}   # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
     # name: (batch per GPU, coarse side, filters, channels, RRDBs)
@@ -167,9 +167,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
-                    help="fp8 = BASELINE configs[4]: forward / data-gradient convs of the critic's 128..1024-channel layers on the MXFP8 "
-                         "MFMA (fp32 accumulate), everything else as in bf16")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8", "fp8c"],
+                    help="fp8 = BASELINE configs[4]: forward / data-gradient convs of the critic's 128..1024-channel layers AND the forward "
+                         "of the generator's dense-block trunk on the MXFP8 MFMA (fp32 accumulate), everything else as in bf16; "
+                         "fp8c = the critic's layers only")
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -199,7 +200,8 @@ def main():
     B, S, F_, cin, nrb = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
-    ops = HipOps("bf16" if args.dtype == "fp8" else args.dtype, f"cuda:{local}", f8_critic=args.dtype == "fp8")
+    is_f8 = args.dtype in ("fp8", "fp8c")
+    ops = HipOps("bf16" if is_f8 else args.dtype, f"cuda:{local}", f8_critic=is_f8, f8_generator=args.dtype == "fp8")
     eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B * world), num_res_blocks=nrb, dist=dist)
     eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))       # seed 0 on every rank
     eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
@@ -268,7 +270,7 @@ def main():
         fl = sum(agg[t][0] for t in halo)
         sec = sum(agg[t][1] for t in halo)
         nl = sum(agg[t][2] for t in halo)
-        peak = MFMA_PEAK_TFLOPS["bf16" if args.dtype == "fp8" else args.dtype]      # gg_halo4w_kernel is a bf16 / fp32 kernel in every mode
+        peak = MFMA_PEAK_TFLOPS["bf16" if is_f8 else args.dtype]      # gg_halo4w_kernel is a bf16 / fp32 kernel in every mode
         ach = fl / sec / 1e12 if sec > 0 else 0.0
         alg_bytes = sum(agg[t][3] for t in halo) / max(nl, 1)
         traffic, traffic_src = pmc_traffic("gg_halo4w_kernel", args)
@@ -295,7 +297,7 @@ def main():
         if f8:      # fp8 mode: the MXFP8 conv launches (quantisation of their operands included in the bracketed time)
             ffl, fsec, fn = sum(agg[t][0] for t in f8), sum(agg[t][1] for t in f8), sum(agg[t][2] for t in f8)
             roofline["fp8_kernel"] = {"kernel": "gg_halo4w_f8_kernel (MXFP8 conv forward / data gradient of the critic's wide layers, operand "
-                                                "quantisation included)", "bound": "mfma", "achieved": round(ffl / fsec / 1e12, 2),
+                                                "quantisation included; with --dtype fp8 also the generator trunk's forward)", "bound": "mfma", "achieved": round(ffl / fsec / 1e12, 2),
                                       "peak": MFMA_PEAK_TFLOPS["fp8"], "unit": "TFLOP/s", "frac": round(ffl / fsec / 1e12 / MFMA_PEAK_TFLOPS["fp8"], 4),
                                       "launches": fn, "share_of_step": round(fsec / elapsed, 3)}
         ops.prof = None
@@ -321,7 +323,7 @@ def main():
                        "work": "1.4*Gf + 10.4*Cf per sample-step, real channels (SURVEY 8(d) counts 1.6*Gf: the generator iteration's "
                                "G(coarse) is the critic iteration's, computed once)",
                        "generator_steps_in_timed_region": gen_steps_timed},
-            "step_mfma_frac": round(w_step * value / world / 1e12 / MFMA_PEAK_TFLOPS["bf16" if args.dtype == "fp8" else args.dtype], 4),
+            "step_mfma_frac": round(w_step * value / world / 1e12 / MFMA_PEAK_TFLOPS["bf16" if is_f8 else args.dtype], 4),
             "losses": {k: scal[k] for k in ("critic_loss", "gp_ret", "g_loss") if k in scal},
             "roofline": roofline, "critic_conv_stack": critic_stack, "kernels": kernels,
         }

@@ -21,7 +21,7 @@ class Epilogue(C.Structure):
                 ("r2", C.c_void_p), ("ldr2", C.c_int64), ("s2", C.c_float),
                 ("mask", C.c_void_p), ("ldmask", C.c_int64), ("mask_slope", C.c_float),
                 ("accumulate", C.c_int), ("mask_bits", C.c_void_p), ("out_bits", C.c_void_p),
-                ("mask_c0", C.c_int), ("mask_last", C.c_int), ("out_q", C.c_void_p), ("out_qs", C.c_void_p)]
+                ("mask_c0", C.c_int), ("mask_last", C.c_int), ("out_q", C.c_void_p), ("out_qs", C.c_void_p), ("ldqs", C.c_int64)]
 
 
 class ConvGeom(C.Structure):
@@ -50,7 +50,7 @@ class MsssimCombine(C.Structure):
 
 
 class F8Operands(C.Structure):
-    _fields_ = [("xq", C.c_void_p), ("xs", C.c_void_p), ("ldxq", C.c_int64), ("wq", C.c_void_p), ("ws", C.c_void_p)]
+    _fields_ = [("xq", C.c_void_p), ("xs", C.c_void_p), ("ldxq", C.c_int64), ("ldxs", C.c_int64), ("wq", C.c_void_p), ("ws", C.c_void_p)]
 
 
 MAX_FIELDS = 8
@@ -97,7 +97,7 @@ _PROTOS = {
     "dg_msssim_finish": [_vp, _i, _i, C.POINTER(MsssimCombine), _vp, _vp],
     "dg_div_vort_sums": [_i, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp],
     "dg_gather_samples": [_i, _vp, _i64, _i, _vp, _i, _vp, _i, _vp],
-    "dg_quant_mxfp8": [_i, _vp, _i64, _i64, _i, _vp, _i64, _vp, _vp],
+    "dg_quant_mxfp8": [_i, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i64, _vp],
     "dg_conv3x3_fwd_f8": [C.POINTER(ConvGeom), C.POINTER(Epilogue), C.POINTER(F8Operands), _vp, _vp],
     "dg_conv3x3_dgrad_f8": [C.POINTER(ConvGeom), C.POINTER(Epilogue), C.POINTER(F8Operands), _vp, _vp],
     "dg_moments": [_vp, _i64, _vp, _vp],

@@ -34,6 +34,7 @@ struct GGArgs {
   const float* bias; const void* r1; const void* r2; const void* mask;
   const void* mask_bits; void* out_bits;     // 1-bit LeakyReLU masks (u16 per lane: 4 fragments x 4 channels), see dg_epilogue
   void* out_q; void* out_qs;                 // MXFP8 copy of the stored output (dg_epilogue.out_q / out_qs)
+  int ldqs, qs_shift;                        // scale bytes per pixel of out_qs; log2(Nout / 16) when that stride is not Nout / 32
   long long ldx, ldw, ldy, ldr1, ldr2, ldmask;
   int M, Hg, Wg, Hs, Ws;
   int cch, kchunks, Cred, ntaps;
@@ -242,7 +243,12 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
       const u32x4_t qv = __builtin_bit_cast(u32x4_t, pack_fp8x16(w, mx_inv_scale(e)));
       __builtin_amdgcn_raw_buffer_store_b128(qv, R.rq, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
       const bool low_half = ((threadIdx.x >> 4) & 1) == 0;
-      __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, R.rqs, (low_half && boff != DG_OOB_OFF) ? boff >> 2 : DG_OOB_OFF, 0, 0);
+      unsigned offqs = boff >> 2;                                   // dense scale rows: (rel * Nout + channel) / 32
+      if (a.ldqs != (a.Nout >> 5)) {                                // a channel slice of a wider tensor (dense-block slab)
+        const unsigned w16 = boff >> 1;                             // rel * (Nout / 16) + channel / 16, Nout / 16 a power of two
+        offqs = (w16 >> a.qs_shift) * (unsigned)a.ldqs + ((w16 & ((1u << a.qs_shift) - 1u)) >> 1);
+      }
+      __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, R.rqs, (low_half && boff != DG_OOB_OFF) ? offqs : DG_OOB_OFF, 0, 0);
     }
   }
 }
@@ -287,7 +293,7 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
     R.rY = rsrc(a.y, a.ldy, ES);
     R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
     R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
-    R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.Nout >> 5, 1);
+    R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.ldqs, 1);
     R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
     int relv[FP];
     bool okv[FP];
@@ -701,7 +707,7 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
   R.rY = rsrc(a.y, a.ldy, ES);
   R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
   R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
-  R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.Nout >> 5, 1);
+  R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.ldqs, 1);
   R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
   const bool xok = tx0 + l15 < a.Wg;
   // every mask word of the wave's tile first (NH halves x 4 rows), before the first store
@@ -762,6 +768,9 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       case 64: run(std::integral_constant<int, 64>{}, htag); break;    // accumulate (dense-block data gradients)
       case 128: run(std::integral_constant<int, 128>{}, htag); break;  // mask of the completed top slice (dense block, conv 5's data gradient)
       case 192: run(std::integral_constant<int, 192>{}, htag); break;  // accumulate, then the completed slice's mask (convs 4..2)
+      case 257: run(std::integral_constant<int, 257>{}, htag); break;  // fp8 mode: bias + LeakyReLU + MXFP8 copy (generator dense-block convs)
+      case 264: run(std::integral_constant<int, 264>{}, htag); break;  // fp8 mode: residual + MXFP8 copy (dense-block output)
+      case 280: run(std::integral_constant<int, 280>{}, htag); break;  // fp8 mode: two residuals + MXFP8 copy (RRDB output)
       case 258: run(std::integral_constant<int, 258>{}, htag); break;  // fp8 mode: 1-bit mask + MXFP8 copy (critic data gradients, tangent forward)
       case 261: run(std::integral_constant<int, 261>{}, htag); break;  // fp8 mode: LeakyReLU + out_bits + MXFP8 copy (critic forward)
       default: run(std::integral_constant<int, -1>{}, htag); break;
@@ -1357,7 +1366,7 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
 // and the same matrix-pipe cycles for twice the channels.  Beside the operands, each K-step needs 4 scale bytes per patch
 // pixel (fetched with the patch into s_ps) and per weight row (a fifth LDS-DMA piece of waves 0/1 into s_ws); lane group g
 // reads byte g.  Output: bf16 through the common epilogue (activations, masks, bit masks as in the bf16 kernel).
-struct F8Args { const unsigned char* xs; const unsigned char* ws; };      // scale strides follow from Cred: Cred/32 per pixel, 9*Cred/32 per weight row
+struct F8Args { const unsigned char* xs; const unsigned char* ws; int ldxs; };   // ldxs: scale bytes per source pixel (Cred/32 unless the source is a slab slice); weights: 9*Cred/32 per row
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 
 template <bool S2>
@@ -1386,7 +1395,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
   const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0,32)
   const int sy_base = S2 ? (ty0 > 0 ? 2 * (ty0 - 1) : 0) : (ty0 - 1 > 0 ? ty0 - 1 : 0);
   const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
-  const int ldxs = a.Cred >> 5, ldws = 9 * (a.Cred >> 5);
+  const int ldxs = f.ldxs, ldws = 9 * (a.Cred >> 5);
   const char* XSb = reinterpret_cast<const char*>(f.xs) + ((long long)img * a.Hs + sy_base) * a.Ws * ldxs;
   const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
   const char* WSb = reinterpret_cast<const char*>(f.ws) + (long long)c0 * ldws;
@@ -1900,7 +1909,7 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void gg_im2col_kernel(const GGAr
     R.rY = rsrc(a.y, a.ldy, ES);
     R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
     R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
-    R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.Nout >> 5, 1);
+    R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.ldqs, 1);
     R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
     unsigned mbv[4];
 #pragma unroll
@@ -2106,13 +2115,21 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     // the MXFP8 copy is written by the 64-channel wave-tile epilogues of bf16 launches: same shape rules as the bit masks
     if ((a.out_q != nullptr) != (a.out_qs != nullptr)) return DG_ERR_BAD_ARG;
     if (a.out_q && (d->dtype != DG_BF16 || d->Nout < 128 || d->Nout % 64 || d->dst_ps)) return DG_ERR_BAD_SHAPE;
+    a.ldqs = ep->ldqs > 0 ? (int)ep->ldqs : d->Nout / 32;
+    a.qs_shift = 0;
+    if (a.out_q && a.ldqs != d->Nout / 32) {        // strided scale rows: the kernel splits the mask-word index by a shift
+      const int n16 = d->Nout / 16;
+      if ((n16 & (n16 - 1)) || a.ldqs < d->Nout / 32) return DG_ERR_BAD_SHAPE;
+      while ((1 << a.qs_shift) < n16) ++a.qs_shift;
+    }
     // bit masks need 64-channel wave tiles (Nout >= 128 selects them in every dispatch path) and plain destinations
     if ((a.mask_bits || a.out_bits) && (d->Nout < 128 || d->Nout % 64 || d->dst_ps || (a.mask_bits && a.mask))) return DG_ERR_BAD_SHAPE;
     if ((a.r1 && a.ldr1 % 4) || (a.r2 && a.ldr2 % 4) || (a.mask && a.ldmask % 4)) return DG_ERR_BAD_SHAPE;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (f8) {
-    F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws};
+    F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws, f8->ldxs > 0 ? (int)f8->ldxs : d->Cred / 32};
+    if (f.ldxs < d->Cred / 32 || f.ldxs % 4) return DG_ERR_BAD_SHAPE;          // the kernel fetches 4 scale bytes per pixel and K-step as one dword
     return gg_launch_f8(a, f, d->N, st);
   }
   static const bool no_im2col = getenv("DG_GG_NOIM2COL") != nullptr;

@@ -38,7 +38,8 @@ template <> struct QLoad<float> {
 // one thread = one block of one row: rows x (C / 32) threads
 template <typename T>
 __global__ void __launch_bounds__(256) quant_mxfp8_kernel(const T* __restrict__ src, long long rows, long long ld, int C,
-                                                          unsigned char* __restrict__ q, long long ldq, unsigned char* __restrict__ sc) {
+                                                          unsigned char* __restrict__ q, long long ldq, unsigned char* __restrict__ sc,
+                                                          long long ldqs) {
   const int nb = C >> 5;
   const long long total = rows * nb;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -55,13 +56,14 @@ __global__ void __launch_bounds__(256) quant_mxfp8_kernel(const T* __restrict__ 
     const float inv = mx_inv_scale(e);
     *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo) = pack_fp8x16(v, inv);
     *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo + 16) = pack_fp8x16(v + 16, inv);
-    sc[r * nb + b] = (unsigned char)e;
+    sc[r * ldqs + b] = (unsigned char)e;
   }
 }
 
 extern "C" int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int64_t ld, int C, void* q, int64_t ldq, void* scales,
-                              void* stream) {
-  if (!src || !q || !scales || rows <= 0 || C <= 0 || C % 128 || ld < C || ldq < C || ldq % 16) return DG_ERR_BAD_SHAPE;
+                              int64_t ldqs, void* stream) {
+  if (ldqs <= 0) ldqs = C / 32;
+  if (!src || !q || !scales || rows <= 0 || C <= 0 || C % 128 || ld < C || ldq < C || ldq % 16 || ldqs < C / 32) return DG_ERR_BAD_SHAPE;
   if ((src_dtype == DG_BF16 && ld % 8) || (src_dtype == DG_F32 && ld % 4)) return DG_ERR_BAD_SHAPE;
   const long long total = (long long)rows * (C / 32);
   long long nb = (total + 255) / 256;
@@ -69,10 +71,10 @@ extern "C" int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int6
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (src_dtype == DG_BF16)
     hipLaunchKernelGGL(quant_mxfp8_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)src, (long long)rows, (long long)ld, C,
-                       (unsigned char*)q, (long long)ldq, (unsigned char*)scales);
+                       (unsigned char*)q, (long long)ldq, (unsigned char*)scales, (long long)ldqs);
   else if (src_dtype == DG_F32)
     hipLaunchKernelGGL(quant_mxfp8_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)src, (long long)rows, (long long)ld, C,
-                       (unsigned char*)q, (long long)ldq, (unsigned char*)scales);
+                       (unsigned char*)q, (long long)ldq, (unsigned char*)scales, (long long)ldqs);
   else return DG_ERR_BAD_DTYPE;
   return dg_check_launch();
 }

@@ -208,7 +208,7 @@ class NativeCritic:
         # layer l), adjoints us[l] (data gradient of layer l), the penalty's tangents, both weight packs -- written by the
         # PRODUCING launch's epilogue (dg_epilogue.out_q) or, for the weights, once per optimizer step; None = not needed
         self.f8 = bool(getattr(o, "f8", False))
-        qbuf = lambda t: (o.zeros(t.numel(), dtype=torch.uint8), o.zeros(t.numel() // 32, dtype=torch.uint8))
+        qbuf = lambda t: (o.zeros(*t.shape, dtype=torch.uint8), o.zeros(*t.shape[:-1], t.shape[-1] // 32, dtype=torch.uint8))
         self.actq = [None] * 8
         self.usq = [None] * 8
         self.wq_f, self.wq_d = [None] * 8, [None] * 8
@@ -219,9 +219,9 @@ class NativeCritic:
                     self.actq[l] = qbuf(self.acts[l])
                 if o.f8_eligible(cv, "dgrad"):
                     self.usq[l] = qbuf(self.us[l])
-                    self.wq_d[l] = (o.zeros(cv.Cout * 9 * cv.Cin, dtype=torch.uint8), o.zeros(cv.Cout * 9 * cv.Cin // 32, dtype=torch.uint8))
+                    self.wq_d[l] = (o.zeros(cv.Cin * 9, cv.Cout, dtype=torch.uint8), o.zeros(cv.Cin * 9, cv.Cout // 32, dtype=torch.uint8))
                 if o.f8_eligible(cv, "fwd"):
-                    self.wq_f[l] = (o.zeros(cv.Cout * 9 * cv.Cin, dtype=torch.uint8), o.zeros(cv.Cout * 9 * cv.Cin // 32, dtype=torch.uint8))
+                    self.wq_f[l] = (o.zeros(cv.Cout * 9, cv.Cin, dtype=torch.uint8), o.zeros(cv.Cout * 9, cv.Cin // 32, dtype=torch.uint8))
             P.after_refresh.append(self._requantise_weights)
 
     def _requantise_weights(self):
@@ -355,8 +355,8 @@ class NativeCritic:
             f8kw, tqn = {}, None
             if self.f8:
                 if self.actq[l] is not None:          # the next layer's tangent forward is an fp8 conv
-                    n = self.acts[l].numel()
-                    tqn = (self._tanq[l & 1][0][:n], self._tanq[l & 1][1][:n // 32])
+                    n, sh = self.acts[l].numel(), self.acts[l].shape
+                    tqn = (self._tanq[l & 1][0][:n].view(sh), self._tanq[l & 1][1][:n // 32].view(*sh[:-1], sh[-1] // 32))
                 f8kw = dict(xq=tq, wq=self.wq_f[l], out_q=tqn)
             if self.act_bits:
                 o.conv_fwd(cv, t, P.w(name), tn, mask_bits=self.act_bits[l], mask_slope=C_SLOPE, **f8kw)
@@ -384,8 +384,8 @@ class NativeGenerator:
         self.nrb, self.nup = num_res_blocks, num_upsample
         F_, S, B = filters, coarse_side, batch
         self.cv_conv1 = Conv(B, S, S, self.cin_p, F_, cin_real=(channels if channels <= 2 else 0), cin_alg=channels)
-        self.cv_b = [Conv(B, S, S, k * F_, F_) for k in range(1, 6)]
-        self.cv_conv2 = Conv(B, S, S, F_, F_)
+        self.cv_b = [Conv(B, S, S, k * F_, F_, net="G") for k in range(1, 6)]      # net="G": fp8-eligible in f8_generator mode
+        self.cv_conv2 = Conv(B, S, S, F_, F_, net="G")
         self.cv_up = [Conv(B, S << u, S << u, F_, 4 * F_, 1, True) for u in range(num_upsample)]
         hs = S << num_upsample
         self.cv_c30 = Conv(B, hs, hs, F_, F_)
@@ -418,6 +418,29 @@ class NativeGenerator:
         self._ring = [o.zeros(B, S, S, 5 * F_) for _ in range(4)]
         self._saved = None
         self._bwd = None
+        # fp8 mode (HipOps(f8_generator=True)): the FORWARD of the dense-block trunk (240 convs + conv2, 84 % of the generator's
+        # flops) runs on the MXFP8 kernel.  Every slab gets an fp8 form [B,S,S,5F] + scales [B,S,S,5F/32] (four rotating ones: the
+        # backward never reads them); conv k's epilogue writes its slice of it, the next conv reads the first k+1 slices.
+        self.f8 = bool(getattr(o, "f8_generator", False)) and all(o.f8_eligible(cv, "fwd") for cv in self.cv_b)
+        self._qring = [(o.zeros(B, S, S, 5 * F_, dtype=torch.uint8), o.zeros(B, S, S, 5 * F_ // 32, dtype=torch.uint8)) for _ in range(4)] if self.f8 else None
+        self._wq = {}
+        if self.f8:
+            P.after_refresh.append(self._requantise_weights)
+
+    def _f8_names(self):
+        for i in range(self.nrb):
+            for j in range(3):
+                for k in range(1, 6):
+                    yield f"res_blocks.{i}.dense_blocks.{j}.b{k}.0", self.cv_b[k - 1]
+        yield "conv2", self.cv_conv2
+
+    def _requantise_weights(self):
+        o, P = self.ops, self.P
+        for name, cv in self._f8_names():
+            if name not in self._wq:
+                self._wq[name] = (o.zeros(cv.Cout * 9, cv.Cin, dtype=torch.uint8), o.zeros(cv.Cout * 9, cv.Cin // 32, dtype=torch.uint8))
+            off, n, _ = P.entries[name + ".weight"]
+            o.quant_mxfp8(P.shadow[off:off + n].view(cv.Cout * 9, cv.Cin), *self._wq[name])
 
     # ---- state_dict interchange ------------------------------------------------------------------
     def _conv_names(self):
@@ -470,6 +493,11 @@ class NativeGenerator:
         Bz = lambda n: P.master(n + ".bias")
         o.conv_fwd(self.cv_conv1, x, W("conv1"), self.out1, bias=Bz("conv1"))
         o.axpby(self._slab(0, save)[..., :F_], self.out1)
+        f8 = self.f8
+        nq = F_ // 32
+        qs = lambda d, c0, c1: (self._qring[d % 4][0][..., c0:c1], self._qring[d % 4][1][..., c0 // 32:c1 // 32])   # fp8 form of slab d, channels [c0, c1)
+        if f8:
+            o.quant_mxfp8(self._slab(0, save)[..., :F_], *qs(0, 0, F_))
         for i in range(self.nrb):
             rrdb_in = self._slab(3 * i, save)[..., :F_]
             for j in range(3):
@@ -477,14 +505,18 @@ class NativeGenerator:
                 slab, nxt = self._slab(d, save), self._slab(d + 1, save)
                 pre = f"res_blocks.{i}.dense_blocks.{j}.b"
                 for k in range(1, 5):
+                    kw = dict(xq=qs(d, 0, k * F_), wq=self._wq[f"{pre}{k}.0"], out_q=qs(d, k * F_, (k + 1) * F_)) if f8 else {}
                     o.conv_fwd(self.cv_b[k - 1], slab[..., :k * F_], W(f"{pre}{k}.0"), slab[..., k * F_:(k + 1) * F_],
-                               bias=Bz(f"{pre}{k}.0"), act=G_SLOPE)
+                               bias=Bz(f"{pre}{k}.0"), act=G_SLOPE, **kw)
                 ep = dict(bias=Bz(f"{pre}5.0"), r1=slab[..., :F_], s1=RES_SCALE)          # generator.py:41
                 if j == 2:
                     ep.update(r2=rrdb_in, s2=RES_SCALE)                                  # generator.py:53
+                if f8:
+                    ep.update(xq=qs(d, 0, 5 * F_), wq=self._wq[f"{pre}5.0"], out_q=qs(d + 1, 0, F_))
                 o.conv_fwd(self.cv_b[4], slab, W(f"{pre}5.0"), nxt[..., :F_], **ep)
+        kw = dict(xq=qs(self.ndrb, 0, F_), wq=self._wq["conv2"]) if f8 else {}
         o.conv_fwd(self.cv_conv2, self._slab(self.ndrb, save)[..., :F_], W("conv2"), self.trunk, bias=Bz("conv2"),
-                   r1=self.out1, s1=1.0)                                                 # generator.py:86-87
+                   r1=self.out1, s1=1.0, **kw)                                           # generator.py:86-87
         cur = self.trunk
         for u in range(self.nup):
             o.conv_fwd(self.cv_up[u], cur, W(f"upsampling.{3 * u}"), self.ups[u], bias=Bz(f"upsampling.{3 * u}"), act=G_SLOPE)

@@ -66,10 +66,12 @@ class HipOps:
 
     name = "hip"
 
-    def __init__(self, dtype="bf16", device="cuda:0", f8_critic=False):
+    def __init__(self, dtype="bf16", device="cuda:0", f8_critic=False, f8_generator=False):
         """``f8_critic``: MXFP8 conv path (BASELINE configs[4]) -- forward and data-gradient convs of critic layers whose
         reduction channels are a multiple of 128 run on the block-scaled fp8 MFMA: their bf16 source tensor and weight pack are
-        quantised on the fly (``dg_quant_mxfp8``), accumulation is fp32, outputs / masks / weight gradients stay bf16."""
+        quantised on the fly (``dg_quant_mxfp8``) unless the caller passes producer-written forms, accumulation is fp32, outputs /
+        masks / weight gradients stay bf16.  ``f8_generator`` (implies ``f8_critic``): also the FORWARD of the generator's
+        dense-block trunk convs (generator.py:24-41; layers tagged net="G")."""
         assert dtype in TORCH_DTYPE
         if not torch.cuda.is_available():
             raise RuntimeError("downgan_amd.ops.HipOps needs a ROCm GPU (no CPU fallback exists)")
@@ -80,7 +82,8 @@ class HipOps:
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.lib = _lib.lib()
         self.prof = None      # optional list of (tag, flops, bytes, start_event, end_event): bench.py's live kernel timing
-        self.f8 = bool(f8_critic)
+        self.f8 = bool(f8_critic or f8_generator)
+        self.f8_generator = bool(f8_generator)
         assert not self.f8 or dtype == "bf16", "the fp8 conv path quantises bf16 tensors"
         self._f8_scratch = {}
 
@@ -175,12 +178,14 @@ class HipOps:
                 assert t.dtype == torch.int16 and t.is_cuda and t.is_contiguous() and tuple(t.shape) == self.bits_shape(out.shape), (name, t.shape, out.shape)
                 setattr(ep, name, t.data_ptr())
         assert not (mask is not None and mask_bits is not None)
-        if out_q is not None:       # (q, scales): MXFP8 copy of the stored output, q with `out`'s pixel stride
-            q, qs = out_q
+        if out_q is not None:       # (q, scales): MXFP8 copy of the stored output -- views with `out`'s shape and strides
+            q, qs = out_q             # (a channel slice of a slab's fp8 form when `out` is a slice of the slab)
             Cc = out.shape[-1]
-            assert out.dtype == torch.bfloat16 and out.is_contiguous() and Cc % 64 == 0 and Cc >= 128
-            assert q.dtype == torch.uint8 and qs.dtype == torch.uint8 and q.numel() == out.numel() and qs.numel() == out.numel() // 32
-            ep.out_q, ep.out_qs = q.data_ptr(), qs.data_ptr()
+            assert out.dtype == torch.bfloat16 and Cc % 64 == 0 and Cc >= 128
+            assert q.dtype == torch.uint8 and qs.dtype == torch.uint8 and q.shape == out.shape and q.stride() == out.stride(), (q.shape, q.stride(), out.stride())
+            assert tuple(qs.shape) == tuple(out.shape[:-1]) + (Cc // 32,) and qs.stride(-1) == 1
+            assert all(qs.stride(i) * out.stride(2) == out.stride(i) * qs.stride(2) for i in range(3)), (qs.stride(), out.stride())
+            ep.out_q, ep.out_qs, ep.ldqs = q.data_ptr(), qs.data_ptr(), qs.stride(2)
         return ep
 
     # ------------------------------------------------------------------ conv family
@@ -192,7 +197,8 @@ class HipOps:
     def f8_eligible(self, cv: Conv, kind):
         """Does this layer's forward ("fwd") / data gradient ("dgrad") run on the MXFP8 kernel in f8 mode?"""
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
-        return self.f8 and cv.net == "C" and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
+        nets = ("C", "G") if (self.f8_generator and kind == "fwd") else ("C",)
+        return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
 
     def conv_fwd(self, cv: Conv, x, w_fwd, y, xq=None, wq=None, **ep):
         """``xq`` / ``wq`` (f8 mode, optional): (q, scales) MXFP8 forms of ``x`` / ``w_fwd`` that a producer already wrote
@@ -227,42 +233,48 @@ class HipOps:
 
     # ------------------------------------------------------------------ MXFP8 conv path
     def quant_mxfp8(self, src, q=None, scales=None):
-        """src: [..., C] (bf16 or fp32, unit channel stride, dense rows of stride ld) -> (q uint8 [rows, C], scales uint8
-        [rows, C/32]): MXFP8, blocks of 32 consecutive channels (csrc/quant.hip)."""
+        """src: [..., C] (bf16 or fp32, unit channel stride; 4-D NHWC with dense pixels, possibly a channel slice of a slab, or
+        2-D rows) -> (q uint8 of src's shape, scales uint8 [..., C/32]): MXFP8, blocks of 32 consecutive channels
+        (csrc/quant.hip).  ``q`` / ``scales`` may be views of wider tensors (a slab's fp8 form)."""
         Cc = src.shape[-1]
-        assert Cc % 128 == 0 and src.stride(-1) == 1 and src.is_cuda
+        assert Cc % 128 == 0 and src.stride(-1) == 1 and src.is_cuda and src.dtype in (torch.float32, torch.bfloat16)
         if src.dim() == 4:
             ld, rows = pix_layout(src)
         else:
-            src2 = src.reshape(-1, Cc)
-            assert src2.data_ptr() == src.data_ptr()
-            ld, rows = src2.stride(0), src2.shape[0]
+            assert src.dim() == 2
+            ld, rows = src.stride(0), src.shape[0]
         if q is None:
-            q = torch.empty(rows, Cc, dtype=torch.uint8, device=self.device)
-            scales = torch.empty(rows, Cc // 32, dtype=torch.uint8, device=self.device)
-        assert q.dtype == torch.uint8 and q.numel() >= rows * Cc and scales.numel() >= rows * (Cc // 32)
+            q = torch.empty(src.shape, dtype=torch.uint8, device=self.device)
+            scales = torch.empty(tuple(src.shape[:-1]) + (Cc // 32,), dtype=torch.uint8, device=self.device)
+        assert q.dtype == torch.uint8 and scales.dtype == torch.uint8 and q.shape == src.shape and q.stride(-1) == 1 and scales.stride(-1) == 1
+        assert tuple(scales.shape) == tuple(src.shape[:-1]) + (Cc // 32,)
+        ldq, ldqs = q.stride(-2), scales.stride(-2)
+        if src.dim() == 4:
+            assert pix_layout(q)[1] == rows and all(scales.stride(i) * ldq == q.stride(i) * ldqs for i in range(3))
         sdt = _lib.DG_F32 if src.dtype == torch.float32 else _lib.DG_BF16
-        assert src.dtype in (torch.float32, torch.bfloat16)
-        check(self.lib.dg_quant_mxfp8(sdt, _ptr(src), rows, ld, Cc, _ptr(q), Cc, _ptr(scales), self._stream()), "dg_quant_mxfp8")
+        check(self.lib.dg_quant_mxfp8(sdt, _ptr(src), rows, ld, Cc, _ptr(q), ldq, _ptr(scales), ldqs, self._stream()), "dg_quant_mxfp8")
         return q, scales
 
-    def _f8_buf(self, key, n):
+    def _f8_buf(self, key, shape):
+        n = 1
+        for d in shape:
+            n *= d
         b = self._f8_scratch.get(key)
         if b is None or b.numel() < n:
             b = self._f8_scratch[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
-        return b
+        return b[:n].view(shape)
 
     def _conv_f8(self, fn, g, e, src, w, nout, cred, dst, xq=None, wq=None):
         """the fp8 conv (forward or data gradient); operands that come without an MXFP8 form are quantised into scratch."""
-        rows = src.numel() // cred
         if xq is None:
-            xq = self.quant_mxfp8(src, self._f8_buf("xq", rows * cred), self._f8_buf("xs", rows * (cred // 32)))
+            xq = self.quant_mxfp8(src, self._f8_buf("xq", tuple(src.shape)), self._f8_buf("xs", tuple(src.shape[:-1]) + (cred // 32,)))
         if wq is None:
-            wv = w.view(nout * 9, cred)
-            wq = self.quant_mxfp8(wv, self._f8_buf("wq", wv.numel()), self._f8_buf("ws", wv.numel() // 32))
-        (xq, xs), (wq, ws) = xq, wq
-        assert xq.numel() >= rows * cred and xs.numel() >= rows * (cred // 32) and wq.numel() >= nout * 9 * cred
-        q = _lib.F8Operands(xq=xq.data_ptr(), xs=xs.data_ptr(), ldxq=cred, wq=wq.data_ptr(), ws=ws.data_ptr())
+            wq = self.quant_mxfp8(w.view(nout * 9, cred), self._f8_buf("wq", (nout * 9, cred)), self._f8_buf("ws", (nout * 9, cred // 32)))
+        (xqq, xs), (wqq, ws) = xq, wq
+        assert xqq.shape == src.shape and xqq.stride(-1) == 1 and tuple(xs.shape) == tuple(src.shape[:-1]) + (cred // 32,), (xqq.shape, xs.shape, src.shape)
+        assert pix_layout(xqq)[1] == pix_layout(src)[1] and all(xs.stride(i) * xqq.stride(2) == xqq.stride(i) * xs.stride(2) for i in range(3))
+        assert wqq.numel() == nout * 9 * cred and wqq.is_contiguous() and ws.numel() == nout * 9 * (cred // 32) and ws.is_contiguous()
+        q = _lib.F8Operands(xq=xqq.data_ptr(), xs=xs.data_ptr(), ldxq=xqq.stride(2), ldxs=xs.stride(2), wq=wqq.data_ptr(), ws=ws.data_ptr())
         return fn(C.byref(g), C.byref(e), C.byref(q), _ptr(dst), self._stream())
 
     def conv_wgrad(self, cv: Conv, x, dy, dw, db=None):

@@ -69,9 +69,12 @@ typedef struct dg_epilogue {
   /* MXFP8 copy of the stored output for the fp8 conv path (see dg_quant_mxfp8 below): out_q [pixel][ld of y] E4M3 bytes
    * (same pixel stride as y, counted in bytes) and out_qs [pixel][Cout/32] E8M0 scale bytes, bit-identical to
    * dg_quant_mxfp8 of the bf16 tensor this launch stores -- the next layer's fp8 conv reads them instead of a separate
-   * quantisation pass.  Both or neither; bf16 launches with Cout % 64 == 0, Cout >= 128, no pixel shuffle. */
+   * quantisation pass.  Both or neither; bf16 launches with Cout % 64 == 0, Cout >= 128, no pixel shuffle.
+   * ldqs: scale bytes per pixel of out_qs (0 = Cout/32, dense); a larger stride addresses a channel slice of a wider tensor
+   * (dense-block slab: y, out_q and out_qs all point at the slice's first channel) and needs Cout/16 to be a power of two. */
   void* out_q;
   void* out_qs;
+  int64_t ldqs;
 } dg_epilogue;
 
 /* Geometry of ONE reference nn.Conv2d(Cin, Cout, kernel_size=3, stride, padding=1) layer
@@ -284,12 +287,14 @@ int dg_gather_samples(int dtype, const void* src, int64_t HW, int c_real, const 
  *   multiple of 128, more than 64 output channels, no pixel shuffle; anything else returns DG_ERR_BAD_SHAPE. */
 typedef struct dg_f8_operands {
   const void* xq;   /* fp8 source, NHWC */
-  const void* xs;   /* its scales [pixels][Cred/32] */
+  const void* xs;   /* its scales [pixels][ldxs] (the first Cred/32 bytes of each row are used) */
   int64_t ldxq;     /* pixel stride of xq in bytes */
+  int64_t ldxs;     /* scale bytes per pixel of xs; 0 = Cred/32 (dense); a multiple of 4 */
   const void* wq;   /* fp8 weight pack [Nout][9][Cred] */
   const void* ws;   /* its scales [Nout][9][Cred/32] */
 } dg_f8_operands;
-int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int64_t ld, int C, void* q, int64_t ldq, void* scales, void* stream);
+int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int64_t ld, int C, void* q, int64_t ldq, void* scales,
+                   int64_t ldqs, void* stream);   /* ldqs: scale bytes per row, 0 = C/32 */
 int dg_conv3x3_fwd_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* y, void* stream);
 int dg_conv3x3_dgrad_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* dx, void* stream);
 

@@ -28,8 +28,9 @@ def _lgrad(y, slope):
 class EmuOps:
     name = "emu"
 
-    def __init__(self, dtype="f32", device="cpu", f8_critic=False):
-        self.f8 = bool(f8_critic)
+    def __init__(self, dtype="f32", device="cpu", f8_critic=False, f8_generator=False):
+        self.f8 = bool(f8_critic or f8_generator)
+        self.f8_generator = bool(f8_generator)
         self.dtype = dtype
         self.tdtype = TORCH_DTYPE[dtype]
         self.dg = DG_DTYPE[dtype]
@@ -140,65 +141,62 @@ class EmuOps:
             self._pack_bits(full, out_bits)
         if out_q is not None:      # MXFP8 copy of the stored (rounded) output; a strided destination is complete after its last class
             q, s, _ = self.mx_quant(y)
-            out_q[0].view(-1)[:q.numel()].copy_(q.reshape(-1))
-            out_q[1].view(-1)[:s.numel()].copy_(s.reshape(-1))
+            out_q[0].copy_(q)
+            out_q[1].copy_(s)
 
     # ---- MXFP8 (csrc/quant.hip): OCP E4M3 elements, one E8M0 scale per block of 32 consecutive channels (OCP MX layout);
     # scale = 2^(floor(log2 amax) - 8)
     @staticmethod
     def mx_quant(x):
-        """x [..., C] -> (q uint8 [rows, C] E4M3 bit patterns, scales uint8 [rows, C/32], dequantised fp32 [..., C])."""
+        """x [..., C] -> (q uint8 [..., C] E4M3 bit patterns, scales uint8 [..., C/32], dequantised fp32 [..., C])."""
         Cc = x.shape[-1]
         assert Cc % 128 == 0
-        v = x.float().reshape(-1, Cc // 128, 4, 32)
+        v = x.float().reshape(-1, Cc // 32, 32)
         amax = v.abs().amax(-1)
         e = (((amax.contiguous().view(torch.int32) >> 23) & 0xff) - 8).clamp(min=0)
         scale = torch.ldexp(torch.ones_like(amax), e - 127)
         q8 = (v / scale[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
         deq = q8.float() * scale[..., None]
-        unblock = lambda t: t.reshape(-1, Cc)
-        return unblock(q8.view(torch.uint8)), e.to(torch.uint8).reshape(-1, Cc // 32), unblock(deq).reshape(x.shape)
+        return (q8.view(torch.uint8).reshape(x.shape), e.to(torch.uint8).reshape(tuple(x.shape[:-1]) + (Cc // 32,)), deq.reshape(x.shape))
 
     def quant_mxfp8(self, src, q=None, scales=None):
         qq, ss, _ = self.mx_quant(src)
         if q is None:
             return qq, ss
-        q.view(-1)[:qq.numel()].copy_(qq.reshape(-1))
-        scales.view(-1)[:ss.numel()].copy_(ss.reshape(-1))
+        q.copy_(qq.view(q.shape))
+        scales.copy_(ss.view(scales.shape))
         return q, scales
 
     def f8_eligible(self, cv, kind):
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
-        return self.f8 and cv.net == "C" and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
+        nets = ("C", "G") if (self.f8_generator and kind == "fwd") else ("C",)
+        return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
 
     @staticmethod
-    def mx_dequant(q, s, shape):
-        """(E4M3 bytes, E8M0 scale bytes) -> fp32 values of `shape`."""
-        Cc = shape[-1]
-        v = q.reshape(-1, Cc // 32, 32).view(torch.float8_e4m3fn).float()
-        sc = torch.ldexp(torch.ones(s.numel()), s.reshape(-1).int() - 127).reshape(-1, Cc // 32, 1)
-        return (v * sc).reshape(shape)
+    def mx_dequant(q, s):
+        """(E4M3 bytes [..., C], E8M0 scale bytes [..., C/32]; any strides) -> fp32 values [..., C]."""
+        Cc = q.shape[-1]
+        v = q.contiguous().view(torch.float8_e4m3fn).float().reshape(-1, Cc // 32, 32)
+        sc = torch.ldexp(torch.ones(s.numel()), s.contiguous().reshape(-1).int() - 127).reshape(-1, Cc // 32, 1)
+        return (v * sc).reshape(q.shape)
 
-    def _f8_operand(self, t, pre, rows, cred):
+    def _f8_operand(self, t, pre):
         """dequantised fp32 value of an operand: from its producer-written MXFP8 form if given, else quantised here."""
-        if pre is not None:
-            q, s = pre
-            return self.mx_dequant(q.reshape(-1)[:rows * cred], s.reshape(-1)[:rows * (cred // 32)], (rows, cred))
-        return self.mx_quant(t.reshape(rows, cred))[2]
+        return self.mx_dequant(*pre).reshape(t.shape) if pre is not None else self.mx_quant(t)[2]
 
     def conv_fwd(self, cv: Conv, x, w_fwd, y, xq=None, wq=None, **ep):
         assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(y.shape) == self.out_shape(cv)
         (d,) = self._plan(cv, 0, pix_layout(x)[0], pix_layout(y)[0])
         if self.f8_eligible(cv, "fwd"):       # fp8 operands, exact products, fp32 accumulation
-            x = self._f8_operand(x, xq, x.numel() // cv.Cin, cv.Cin).reshape(x.shape)
-            w_fwd = self._f8_operand(w_fwd, wq, cv.Cout * 9, cv.Cin)
+            x = self._f8_operand(x, xq)
+            w_fwd = self._f8_operand(w_fwd.view(cv.Cout * 9, cv.Cin), wq)
         self._gather_gemm(d, x, w_fwd, y, **ep)
 
     def conv_dgrad(self, cv: Conv, dy, w_dgrad, dx, xq=None, wq=None, **ep):
         assert tuple(dx.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(dy.shape) == self.out_shape(cv)
         if self.f8_eligible(cv, "dgrad"):
-            dy = self._f8_operand(dy, xq, dy.numel() // cv.Cout, cv.Cout).reshape(dy.shape)
-            w_dgrad = self._f8_operand(w_dgrad, wq, cv.Cin * 9, cv.Cout)
+            dy = self._f8_operand(dy, xq)
+            w_dgrad = self._f8_operand(w_dgrad.view(cv.Cin * 9, cv.Cout), wq)
         for d in self._plan(cv, 1, pix_layout(dx)[0], pix_layout(dy)[0]):
             self._gather_gemm(d, dy, w_dgrad, dx, **ep)
 

@@ -56,3 +56,25 @@ def test_engine_fp8_mode_only_touches_wide_critic_convs():
     assert a["c_real_mean"] != b["c_real_mean"]                                      # the critic did go through fp8 ...
     assert abs(a["c_real_mean"] - b["c_real_mean"]) < 0.05 * max(abs(a["c_real_mean"]), 0.05)   # ... and stayed close
     assert abs(a["gp_ret"] - b["gp_ret"]) < 1e-2 * a["gp_ret"]
+
+
+def test_generator_fp8_trunk_on_emulated_ops():
+    """f8_generator: the dense-block trunk's forward reads / writes the slabs' fp8 forms (slices of a [B,S,S,5F] byte tensor with
+    strided scale rows); result close to the plain forward, first conv and tail untouched."""
+    from downgan_amd import synthetic
+    from downgan_amd.engine import NativeGenerator
+    from downgan_amd.layout import nchw_to_nhwc_padded
+    torch.set_num_threads(4)
+    B, S, F_, cin, nrb = 1, 8, 128, 2, 1
+    coarse, _ = synthetic.tiles(B, cin, S)
+    xc = nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.float32)
+    outs = {}
+    for f8 in (False, True):
+        G = NativeGenerator(EmuOps("f32", f8_generator=f8), F_, cin, B, S, num_res_blocks=nrb)
+        assert G.f8 == f8
+        G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))
+        outs[f8] = (G.forward(xc, save=f8).clone(), G.out1.clone(), G.trunk.clone())
+    assert torch.equal(outs[False][1], outs[True][1])                         # conv1 is not an fp8 layer
+    d = (outs[True][2] - outs[False][2]).norm() / outs[False][2].norm()
+    assert 0 < float(d) < 0.1, float(d)                                        # trunk went through fp8 and stayed close
+    assert float((outs[True][0] - outs[False][0]).norm() / outs[False][0].norm()) < 0.1
