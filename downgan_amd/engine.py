@@ -424,6 +424,7 @@ class NativeGenerator:
         self.f8 = bool(getattr(o, "f8_generator", False)) and all(o.f8_eligible(cv, "fwd") for cv in self.cv_b)
         self._qring = [(o.zeros(B, S, S, 5 * F_, dtype=torch.uint8), o.zeros(B, S, S, 5 * F_ // 32, dtype=torch.uint8)) for _ in range(4)] if self.f8 else None
         self._wq = {}
+        self._qlast = None
         if self.f8:
             P.after_refresh.append(self._requantise_weights)
 
@@ -494,8 +495,13 @@ class NativeGenerator:
         o.conv_fwd(self.cv_conv1, x, W("conv1"), self.out1, bias=Bz("conv1"))
         o.axpby(self._slab(0, save)[..., :F_], self.out1)
         f8 = self.f8
-        nq = F_ // 32
-        qs = lambda d, c0, c1: (self._qring[d % 4][0][..., c0:c1], self._qring[d % 4][1][..., c0 // 32:c1 // 32])   # fp8 form of slab d, channels [c0, c1)
+        def qs(d, c0, c1):
+            """fp8 form (bytes, scales) of channels [c0, c1) of slab d, with that slab's strides"""
+            if save and d == self.ndrb:           # the saved trunk output is an F-wide tensor of its own, not a 5F slab
+                if self._qlast is None:
+                    self._qlast = (o.zeros(self.B, self.S, self.S, F_, dtype=torch.uint8), o.zeros(self.B, self.S, self.S, F_ // 32, dtype=torch.uint8))
+                return self._qlast
+            return self._qring[d % 4][0][..., c0:c1], self._qring[d % 4][1][..., c0 // 32:c1 // 32]
         if f8:
             o.quant_mxfp8(self._slab(0, save)[..., :F_], *qs(0, 0, F_))
         for i in range(self.nrb):
