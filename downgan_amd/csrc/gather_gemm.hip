@@ -1980,13 +1980,15 @@ static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------ host side
-static int gg_validate(const dg_gg_desc* d, bool f8 = false) {
+static int gg_validate(const dg_gg_desc* d, bool f8 = false, bool compact_src = false) {
   if (d->dtype != DG_F32 && d->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
   const int epc = f8 ? 16 : d->dtype == DG_F32 ? 4 : 8;
   if (d->N <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Hd <= 0 || d->Wd <= 0) return DG_ERR_BAD_SHAPE;
   if (d->Cred <= 0 || d->Cred % 8 || d->Nout <= 0 || d->Nout % 16) return DG_ERR_BAD_SHAPE;
   if (d->ntaps < 1 || d->ntaps > 9) return DG_ERR_BAD_SHAPE;
-  if (d->lds % epc || d->ldd % 4 || d->ldw % epc) return DG_ERR_BAD_SHAPE;
+  // compact_src: the im2col kernel gathers single (channel 0, channel 1) pairs, so its source may be a tensor that stores the
+  // real channels only (pixel stride 2: one dword in bf16) instead of the 16-channel padded form -- 8x fewer cache lines per gather
+  if ((compact_src ? d->lds % 2 || d->lds < 2 : d->lds % epc) || d->ldd % 4 || d->ldw % epc) return DG_ERR_BAD_SHAPE;
   for (int t = 0; t < d->ntaps; ++t) {
     if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1) return DG_ERR_BAD_ARG;
     if (d->tap_w[t] < 0 || d->tap_w[t] > 8) return DG_ERR_BAD_ARG;
@@ -2082,7 +2084,7 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
                             bool im2col_small, const dg_f8_operands* f8 = nullptr) {
   if (!d || !x || !w || !y) return DG_ERR_BAD_ARG;
   if (f8 && (d->dtype != DG_BF16 || !f8->xs || !f8->ws || d->Cred % 128)) return DG_ERR_BAD_SHAPE;
-  int rc = gg_validate(d, f8 != nullptr);
+  int rc = gg_validate(d, f8 != nullptr, im2col_small);
   if (rc) return rc;
   const int epc = f8 ? 16 : d->dtype == DG_F32 ? 4 : 8;
   GGArgs a{};

@@ -205,7 +205,8 @@ class HipOps:
         (``out_q=`` of the previous layer's launch, ``quant_mxfp8`` of the weight pack after an optimizer step); without them
         the operands are quantised on the fly."""
         self._act(x); self._act(y); self._act(w_fwd)
-        assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin), (x.shape, cv)
+        # layers with <= 2 real input channels (im2col kernel) also take the COMPACT form [N, H, W, cin_real] of their input
+        assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin) or (cv.cin_real and tuple(x.shape) == (cv.N, cv.H, cv.W, 2) and cv.stride == 1), (x.shape, cv)
         assert tuple(y.shape) == self.out_shape(cv), (y.shape, cv)
         assert w_fwd.numel() == cv.Cout * 9 * cv.Cin and w_fwd.is_contiguous()
         g = self._geom(cv, pix_layout(x)[0], pix_layout(y)[0])
