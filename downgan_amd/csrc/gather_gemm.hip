@@ -1369,15 +1369,18 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
 struct F8Args { const unsigned char* xs; const unsigned char* ws; int ldxs; };   // ldxs: scale bytes per source pixel (Cred/32 unless the source is a slab slice); weights: 9*Cred/32 per row
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 
-template <bool S2>
-__global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, const F8Args f, int tiles_x, int tiles_y) {
+template <bool S2, int NW = 4>       // NW = 8: 256-channel tile, two channel halves on one patch (see gg_halo4w_kernel)
+__global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a, const F8Args f, int tiles_x, int tiles_y) {
   constexpr int EPC = 16, ES = 1;
+  constexpr int NT = 64 * NW, RPP = NT / 8;
   constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
-  constexpr int BC = 128, KC = 8;                                        // 8 chunks per row: 128 fp8 channels
+  constexpr int BC = 32 * NW, KC = 8;                                    // 8 chunks per row: 128 fp8 channels
   constexpr int PITCH = KC * 16 + 16;                                    // 144 B patch rows
   constexpr int WROW = KC * 16;                                          // 128 B weight rows, chunk c of row r at c ^ ((r >> 1) & 7)
-  constexpr int NPL = (PROWS * KC + 255) / 256;                          // 11 patch chunks per thread
-  constexpr int NWL = BC * KC / 256;                                     // 4 weight pieces per wave and step
+  constexpr int NPL = (PROWS * KC + NT - 1) / NT;                        // 11 (6) patch chunks per thread
+  constexpr int NPS = (PROWS + NT - 1) / NT;                             // 2 (1) patch scale words per thread
+  constexpr int NWL = BC * KC / NT;                                      // 4 weight pieces per wave and step
+  constexpr int NSW = BC / 64;                                           // waves that carry distinct scale pieces
   extern __shared__ __attribute__((aligned(16))) char dsm4f8[];
   char* const s_patch = dsm4f8;                                // [PROWS][PITCH]
   char* const s_w = dsm4f8 + PROWS * PITCH;                    // [2][BC][WROW]
@@ -1392,7 +1395,8 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
   const int ty0 = (rest % tiles_y) * TH;
   const int img = rest / tiles_y;
   const int c0 = tile_c * BC;
-  const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0,32)
+  const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0, RPP)
+  const int wq = wave & 3, wh = wave >> 2;        // tile rows 4*wq.., channel half wh (0 unless NW = 8)
   const int sy_base = S2 ? (ty0 > 0 ? 2 * (ty0 - 1) : 0) : (ty0 - 1 > 0 ? ty0 - 1 : 0);
   const char* Xb = reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
   const int ldxs = f.ldxs, ldws = 9 * (a.Cred >> 5);
@@ -1417,7 +1421,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
   }
   unsigned wsoff;                                 // scale piece (waves 0 and 1): LDS row wave*64 + lane
   {
-    int row = perm64((wave & 1) * 64 + lane);
+    int row = perm64((wave & (NSW - 1)) * 64 + lane);
     if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;
     wsoff = (unsigned)(row * ldws);
   }
@@ -1426,7 +1430,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
     return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
   };
   u32x4_t rp[NPL];
-  unsigned rps[2];
+  unsigned rps[NPS];
   auto load_patch = [&](int vcb) {
     const int plane = plane_of(vcb), cb = vcb - plane * ncbr;
     const int ppy = plane >> 1, ppx = plane & 1;
@@ -1436,7 +1440,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
     asm volatile("" : "+v"(r0v));
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      const int pr = r0v + 32 * i;
+      const int pr = r0v + RPP * i;
       const int py = pr / PW, px = pr - py * PW;
       const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
       const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
@@ -1445,8 +1449,8 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {                 // scale words of patch rows tid and tid + 256
-      const int pr = tid + 256 * i;
+    for (int i = 0; i < NPS; ++i) {               // scale words of patch rows tid (and tid + 256)
+      const int pr = tid + NT * i;
       const int py = pr / PW, px = pr - py * PW;
       const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
       const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
@@ -1458,11 +1462,12 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      const int pr = r0 + 32 * i;
-      if (pr < PROWS) *reinterpret_cast<uint4*>(st_base + i * 32 * PITCH) = __builtin_bit_cast(uint4, rp[i]);
+      const int pr = r0 + RPP * i;
+      if (pr < PROWS) *reinterpret_cast<uint4*>(st_base + i * RPP * PITCH) = __builtin_bit_cast(uint4, rp[i]);
     }
-    *reinterpret_cast<unsigned*>(s_ps + tid * 4) = rps[0];
-    if (tid + 256 < PROWS) *reinterpret_cast<unsigned*>(s_ps + (tid + 256) * 4) = rps[1];
+#pragma unroll
+    for (int i = 0; i < NPS; ++i)
+      if (tid + NT * i < PROWS) *reinterpret_cast<unsigned*>(s_ps + (tid + NT * i) * 4) = rps[i];
   };
   typedef int i32x4h_t __attribute__((ext_vector_type(4)));
   i32x4h_t w_rs, ws_rs;
@@ -1484,7 +1489,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
     ws_rs[2] = (int)DG_OOB_OFF;
     ws_rs[3] = 0x00020000;
     ws_dst = __builtin_amdgcn_readfirstlane(
-        (int)(unsigned long long)((__attribute__((address_space(3))) char*)(s_ws + slot * (BC * 4) + (wave & 1) * 256)));
+        (int)(unsigned long long)((__attribute__((address_space(3))) char*)(s_ws + slot * (BC * 4) + (wave & (NSW - 1)) * 256)));
   };
   auto dma_piece = [&](int i) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
@@ -1503,7 +1508,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
     dma_scales();
   };
   auto barrier_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
-  auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); __syncthreads(); };   // 11 patch chunks + 2 scale words
+  auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPL + NPS) : "memory"); __syncthreads(); };   // patch chunks + scale words
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -1513,9 +1518,9 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
 
   const char* fa_k[2];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) fa_k[kk] = s_w + l15 * WROW + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) * 16);
+  for (int kk = 0; kk < 2; ++kk) fa_k[kk] = s_w + (wh * 128 + l15) * WROW + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) * 16);
   const char* const fb_lane = s_patch + l15 * PITCH + g * 16;
-  const char* const sa_lane = s_ws + l15 * 4 + g;
+  const char* const sa_lane = s_ws + (wh * 128 + l15) * 4 + g;
   const char* const sb_lane = s_ps + l15 * 4 + g;
   // a lane's 32-byte operand = chunk g of the row's first and second 64-byte half, assembled into ONE 8-register value right
   // at the loads (a loop-carried pair of uint4 made the compiler copy every fragment into a fresh tuple: 32 v_mov per step
@@ -1560,7 +1565,7 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
   auto patch_row = [&](int vcb_, int tap_) {
     const unsigned code = tap_code(vcb_, tap_);
     const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
-    return (wave * 4 + 1 + dy) * PW + 1 + dx;
+    return (wq * 4 + 1 + dy) * PW + 1 + dx;
   };
 
   load_patch(0);
@@ -1613,18 +1618,19 @@ __global__ __launch_bounds__(256, 2) void gg_halo4w_f8_kernel(const GGArgs a, co
     __builtin_amdgcn_sched_barrier(0);
     tap = ntap; cb = ncbn;
   }
-  halo_epilogue<bf16_t, 2>(a, acc, img, ty0, tx0, c0, wave, 0, l15, g);
+  halo_epilogue<bf16_t, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
 }
 
-template <bool S2>
+template <bool S2, int NW = 4>
 static int gg_launch_halo4w_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st) {
-  constexpr int LDS_BYTES = 324 * 144 + 2 * 128 * 128 + 2 * 128 * 4 + 324 * 4;
-  DG_SET_MAX_LDS_ONCE((&gg_halo4w_f8_kernel<S2>), LDS_BYTES);
+  constexpr int BC = 32 * NW;
+  constexpr int LDS_BYTES = 324 * 144 + 2 * BC * 128 + 2 * BC * 4 + 324 * 4;
+  DG_SET_MAX_LDS_ONCE((&gg_halo4w_f8_kernel<S2, NW>), LDS_BYTES);
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
-  a.nct = (unsigned)((a.Nout + 127) / 128);
+  a.nct = (unsigned)((a.Nout + BC - 1) / BC);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
   g_last_kinds |= 32;
-  hipLaunchKernelGGL((gg_halo4w_f8_kernel<S2>), dim3(a.nwg), dim3(256), LDS_BYTES, st, a, f, tiles_x, tiles_y);
+  hipLaunchKernelGGL((gg_halo4w_f8_kernel<S2, NW>), dim3(a.nwg), dim3(64 * NW), LDS_BYTES, st, a, f, tiles_x, tiles_y);
   return dg_check_launch();
 }
 
@@ -2075,7 +2081,11 @@ static int gg_launch_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st) {
   if (a.sy_mul == 1 && a.sx_mul == 1 && a.Hs == a.Hg && a.Ws == a.Wg) return gg_launch_halo4w_f8<false>(a, f, N, st);
   if (a.sy_mul == 2 && a.sx_mul == 2 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1) {
     GGArgs b = a;
-    if (regroup_taps_by_plane(b)) return gg_launch_halo4w_f8<true>(b, f, N, st);
+    if (regroup_taps_by_plane(b)) {
+      static const bool no8w = getenv("DG_GG_NO8W") != nullptr;
+      if (!no8w && b.Nout % 256 == 0) return gg_launch_halo4w_f8<true, 8>(b, f, N, st);
+      return gg_launch_halo4w_f8<true>(b, f, N, st);
+    }
   }
   return DG_ERR_BAD_SHAPE;
 }

@@ -198,3 +198,26 @@ def test_cfg4_six_channel_full_tile_fp32():
         assert rel(got[k], ref[k]) < 1e-4, (k, got[k], ref[k])
     k = "conv1.weight"       # the layer that differs from cfg2
     assert float((ggn[k] - gg[k]).norm() / gg[k].norm()) < 2e-3, k
+
+
+def test_fp32_two_steps_with_updates_full_tile():
+    """Two train steps WITH both Adam updates at BASELINE configs[1] shapes (batch 1): step 0 = critic + generator iteration,
+    step 1 = critic iteration on the updated networks (wasserstein.py:131-147).  Exercises the fused Adam over the 438 M / 108 M
+    parameter buffers, the bf16-free fp32 weight repacks and the one-G(coarse)-per-generator-step schedule at full widths;
+    scalars of BOTH steps within 1e-4 of the oracle."""
+    pg, pc, tc, tf = _inputs(2)
+    _threads()
+    orc = ref_step.OracleTrainer(pg, pc, ref_step.HP(batch_size=B), num_res_blocks=NRB)
+    eng, xc, xf = _engine("f32", 2, pg, pc, tc, tf)
+    for step in range(2):
+        alpha = torch.from_numpy(synthetic.alpha(B, step))
+        ref = orc.train_step(tc, tf, alpha)
+        ran_g = eng.train_step(xc, xf, alpha.cuda())
+        got = eng.read_scalars(ran_g)
+        assert ran_g == (step == 0)
+        for k in ("c_real_mean", "c_fake_mean", "gp_ret", "critic_loss") + (("g_loss", "content_loss") if ran_g else ()):
+            assert rel(got[k], ref[k]) < 1e-4, (step, k, got[k], ref[k])
+    # post-update parameters: norms (entries whose gradient is rounding noise may move by +-lr in either run, cf. test_step_gpu)
+    sd = eng.C.state_dict()
+    for k, v in orc.PC.items():
+        assert rel(float(sd[k].double().norm()), float(v.detach().double().norm())) < 5e-5, k
