@@ -14,7 +14,12 @@ pre-allocated once ("caller owns memory").  The maths follows the reference:
 * Critic step / GP / generator step — reference DoWnGAN/GAN/wasserstein.py:27-117, see
   ``TrainEngine``.
 
-LeakyReLU'(z) is recovered from the saved activation (sign(phi(z)) == sign(z)), so no masks are stored.
+LeakyReLU'(z) is recovered from the saved activation (sign(phi(z)) == sign(z)); the critic at >= 128-channel widths keeps
+1-bit masks beside its activations instead (16x fewer bytes in the HBM-bound data-gradient / tangent epilogues).
+
+Precision modes (``ops.dtype`` / ``ops.f8``): "f32" exact-fp32 MFMA (parity), "bf16" (throughput; fp32 masters and Adam), and
+bf16 with the MXFP8 conv path (BASELINE configs[4]): the critic's wide convs forward + data gradient, optionally the forward
+of the generator's dense-block trunk, read fp8 forms that the producing launch's epilogue wrote.
 """
 from __future__ import annotations
 
