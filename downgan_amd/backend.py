@@ -10,4 +10,8 @@ from .ops import HipOps
 
 
 def make_ops(dtype, device):
+    """dtype: "bf16" (default precision of the mirrors), "f32" (exact-fp32 parity mode), "fp8" (bf16 + the MXFP8 conv path for the
+    critic's wide convs and the generator trunk's forward, BASELINE configs[4]) or "fp8c" (critic only)."""
+    if dtype in ("fp8", "fp8c"):
+        return HipOps("bf16", device, f8_critic=True, f8_generator=dtype == "fp8")
     return HipOps(dtype, device)

@@ -191,3 +191,21 @@ def test_fp8_generator_trunk_matches_emulation():
     G.P.zero_grad()
     G.backward(xc, dfake)                                                       # bf16 backward from the saved slabs
     assert float(G.P.g.abs().sum()) > 0 and bool(torch.isfinite(G.P.g).all())
+
+
+def test_mirrors_accept_fp8_dtype():
+    """Generator / Critic / WassersteinGAN mirrors with dtype="fp8": the drop-in API reaches the MXFP8 path."""
+    import math
+    from downgan_amd import synthetic
+    from downgan_amd.GAN.wasserstein import WassersteinGAN
+    from downgan_amd.networks.critic import Critic
+    from downgan_amd.networks.generator import Generator
+    B, S, F_ = 2, 16, 128
+    G = Generator(F_, 8 * S, 2, 2, num_res_blocks=1, dtype="fp8")
+    C = Critic(F_, 8 * S, 2, dtype="fp8")
+    tr = WassersteinGAN(G, C)
+    coarse, fine = synthetic.tiles(B, 2, S)
+    out = tr._critic_train_iteration(torch.from_numpy(coarse), torch.from_numpy(fine), alpha=synthetic.alpha(B, 0), _keep_g=True)
+    out.update(tr._generator_train_iteration(torch.from_numpy(coarse), torch.from_numpy(fine), _reuse_g=True))
+    assert tr._engine.C.f8 and tr._engine.G.f8
+    assert all(math.isfinite(v) for v in out.values()), out
