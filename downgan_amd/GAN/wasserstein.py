@@ -5,7 +5,8 @@ Differences, all additive: the iteration methods RETURN the scalars the referenc
 (:46-50, :74-78); ``alpha`` can be injected into ``_critic_train_iteration`` / ``_gp`` (the reference
 draws it from the device RNG at :91); Adam is the fused native kernel; when ``torch.optim.Adam`` objects
 built the reference's way (stage.py:63-64 over ``G.parameters()`` / ``C.parameters()``) are passed, their lr / betas /
-eps are adopted, otherwise ``config.hyperparams`` applies (the arguments may be None).  mlflow logging / plotting of the reference's epoch loop (:140-179) is out of scope.
+eps are adopted, otherwise ``config.hyperparams`` applies (the arguments may be None).  The epoch loop keeps the reference's per-batch metrics pass, test-set pass, epoch means and per-epoch checkpoints
+(:138-179) with mlflow / plotting replaced by return values, ``metrics_log`` and plain files.
 """
 from __future__ import annotations
 
@@ -37,6 +38,7 @@ class WassersteinGAN:
         self._engine = None
         self._stage = None
         self.last = {}
+        self.metrics_log = []
 
     def _eng(self, coarse, fine):
         B, cin, S, _ = coarse.shape
@@ -111,24 +113,53 @@ class WassersteinGAN:
         xc, xf = self._to_native(e, coarse, fine)
         return e.metrics_pass(xc, xf)
 
+    # what the reference's epoch loop does beside the two iterations (wasserstein.py:138-179), switchable because it costs one
+    # extra G forward + two critic forwards per batch: the per-batch metrics pass on the train set, the same pass over the test
+    # set at the epoch's end, per-epoch means (post_epoch_metric_mean), and the per-epoch checkpoint of both networks
+    log_metrics = True
+    checkpoint_dir = None        # e.g. "artifacts": <dir>/Critic/Critic_<epoch>/state_dict.pth (mlflow_epoch.py:65-69 without mlflow)
+
+    @staticmethod
+    def _metric_means(rows):
+        keys = [k for k in ("MAE", "MSE", "MSSSIM", "Wass") if rows and rows[0].get(k) is not None]
+        return {k: sum(r[k] for r in rows) / len(rows) for k in keys}
+
     def _train_epoch(self, dataloader, testdataloader=None, epoch=0):
-        """wasserstein.py:120-147 without the metrics / plotting / checkpoint side effects."""
-        log = []
+        """wasserstein.py:120-179: every batch = critic iteration, generator iteration when num_steps % critic_iterations == 0
+        (same batch), metrics pass (:140-146); then the epoch means of the train metrics, the metrics over the test loader
+        (:157-170) and the checkpoint (:178).  Plotting (gen_grid_images) and mlflow are out of scope; the per-step scalars are
+        returned and the epoch summary is appended to ``self.metrics_log``."""
+        log, train_metrics, test_metrics = [], [], []
         for data in dataloader:
             coarse, fine = data[0], data[1]
             gen_step = self.num_steps % hp.critic_iterations == 0                 # :136
             out = dict(self._critic_train_iteration(coarse, fine, _keep_g=gen_step))
             if gen_step:
                 out.update(self._generator_train_iteration(coarse, fine, _reuse_g=True))
+            if self.log_metrics:
+                train_metrics.append(self.gen_batch_and_log_metrics(coarse, fine))   # :140-146
             self.num_steps += 1
             if self._engine is not None:
                 self._engine.num_steps = self.num_steps
             log.append(out)
+        summary = {"epoch": epoch}
+        if self.log_metrics:
+            summary["train"] = self._metric_means(train_metrics)                     # :150
+            if testdataloader is not None:
+                for data in testdataloader:                                          # :157-168
+                    if data[0].shape[0] == self._engine.B:                           # full batches only (buffers are shape-bound)
+                        test_metrics.append(self.gen_batch_and_log_metrics(data[0], data[1]))
+                summary["test"] = self._metric_means(test_metrics)                   # :170
+        if self.checkpoint_dir is not None:
+            from ..checkpoint import log_network_models
+            summary["checkpoints"] = log_network_models(self.C, self.G, epoch, self.checkpoint_dir)   # :178
+        self.metrics_log.append(summary)
         return log
 
     def train(self, dataloader, testdataloader=None, epochs=None):
         """wasserstein.py:181-189."""
         self.num_steps = 0
+        self.metrics_log = []
         history = []
         for epoch in range(hp.epochs if epochs is None else epochs):
             history.append(self._train_epoch(dataloader, testdataloader, epoch))

@@ -46,6 +46,10 @@ def check(ns, batch=2, n=4):
     assert {"critic_loss", "gp_ret", "g_loss", "content_loss"} <= set(step0) and "g_loss" not in step1   # generator on step % 5 == 0
     assert all(math.isfinite(v) for v in step0.values())
     assert set(ns["d"]) == {"MAE", "MSE", "MSSSIM", "Wass"} and all(len(v) == 1 and math.isfinite(v[0]) for v in ns["d"].values())
+    # the epoch loop's own metrics (wasserstein.py:138-170): train means over both batches, test means over the test loader
+    (ep,) = ns["trainer"].metrics_log
+    assert ep["epoch"] == 0 and set(ep["train"]) == {"MAE", "MSE", "MSSSIM", "Wass"} == set(ep["test"])
+    assert all(math.isfinite(v) for v in list(ep["train"].values()) + list(ep["test"].values()))
     assert ns["fake"].shape == ns["real"].shape and ns["fake"].dtype == torch.float32
     # Adam as configured through torch.optim.Adam was adopted by the native trainer, and it did move the parameters
     e = ns["trainer"]._engine
@@ -86,3 +90,35 @@ def test_module_surface_without_a_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):          # no CPU fallback: the forward needs the HIP backend
             G(torch.zeros(1, 2, 16, 16))
+
+
+def test_epoch_loop_checkpoints_both_networks(monkeypatch, tmp_path):
+    """wasserstein.py:178 / mlflow_epoch.py:65-69 without mlflow: <dir>/<Net>/<Net>_<epoch>/state_dict.pth per epoch, in the
+    reference's format (loads back into a fresh mirror)."""
+    from downgan_amd import backend, synthetic
+    from downgan_amd.GAN import losses
+    from downgan_amd.GAN.dataloader import NetCDFSR
+    from downgan_amd.GAN.wasserstein import WassersteinGAN
+    from downgan_amd.checkpoint import load_state_dict
+    from downgan_amd.networks.critic import Critic
+    from downgan_amd.networks.generator import Generator
+    from oracle.emu_ops import EmuOps
+    import downgan_amd.config.hyperparams as hp
+    monkeypatch.setattr(backend, "make_ops", lambda dtype, device: EmuOps("f32"))
+    monkeypatch.setattr(losses, "_ops", {})
+    monkeypatch.setattr(hp, "batch_size", 2)
+    torch.set_num_threads(4)
+    coarse, fine = synthetic.tiles(2, 2, 16, seed=5)
+    G, C = Generator(16, 128, 2, 2, num_res_blocks=1), Critic(16, 128, 2)
+    tr = WassersteinGAN(G, C)
+    tr.log_metrics = False
+    tr.checkpoint_dir = str(tmp_path)
+    dl = torch.utils.data.DataLoader(NetCDFSR(torch.from_numpy(coarse), torch.from_numpy(fine)), batch_size=2)
+    tr.train(dl, None, epochs=2)
+    assert [m["epoch"] for m in tr.metrics_log] == [0, 1] and "train" not in tr.metrics_log[0]
+    for name, net, fresh in (("Critic", C, Critic(16, 128, 2)), ("Generator", G, Generator(16, 128, 2, 2, num_res_blocks=1))):
+        path = tmp_path / name / f"{name}_1" / "state_dict.pth"
+        assert path.exists() and (tmp_path / name / f"{name}_0" / "state_dict.pth").exists()
+        load_state_dict(fresh, str(path))
+        a, b = net.state_dict(), fresh.state_dict()
+        assert all(torch.equal(a[k], b[k]) for k in a)
