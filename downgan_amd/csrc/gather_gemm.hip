@@ -1522,45 +1522,23 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
   const char* const fb_lane = s_patch + l15 * PITCH + g * 16;
   const char* const sa_lane = s_ws + (wh * 128 + l15) * 4 + g;
   const char* const sb_lane = s_ps + l15 * 4 + g;
-  // a lane's 32-byte operand = chunk g of the row's first and second 64-byte half, assembled into ONE 8-register value right
-  // at the loads (a loop-carried pair of uint4 made the compiler copy every fragment into a fresh tuple: 32 v_mov per step
-  // and the fragments live twice)
+  // A lane's 32-byte operand = chunk g of the row's first and second 64-byte half.  All fragments of a step are read and
+  // consumed INSIDE the step (nothing is carried around the loop: a loop-carried 8-register value gets split into two
+  // 4-register halves by SROA and copied back together, 32 v_mov per step), and no read result is ever passed through an
+  // asm statement (that forces a full s_waitcnt lgkmcnt(0) right behind the read -- the first version of this kernel
+  // paid two serialised LDS latencies per weight fragment that way).
   auto ld32 = [](const char* p0, const char* p1) {
     const uint4 lo = *reinterpret_cast<const uint4*>(p0), hi = *reinterpret_cast<const uint4*>(p1);
     i32x8_t o;
     o[0] = (int)lo.x; o[1] = (int)lo.y; o[2] = (int)lo.z; o[3] = (int)lo.w;
     o[4] = (int)hi.x; o[5] = (int)hi.y; o[6] = (int)hi.z; o[7] = (int)hi.w;
-    asm volatile("" : "+v"(o));        // pin the value to one 256-bit register tuple (otherwise SROA splits it across the loop phi again)
     return o;
   };
-  i32x8_t fb[4];
-  int sb[4];
-  auto read_b = [&](const char* pb, int prow0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fb[i] = ld32(pb + i * PW * PITCH, pb + i * PW * PITCH + 64);
-      sb[i] = *reinterpret_cast<const unsigned char*>(sb_lane + (prow0 + i * PW) * 4);
-    }
-  };
-  auto mma_pair = [&](int pa, int slot, int j0) {          // two weight fragments x four pixel rows
-    i32x8_t fa[2];
-    int sa[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      fa[q] = ld32(fa_k[0] + pa + (j0 + q) * 16 * WROW, fa_k[1] + pa + (j0 + q) * 16 * WROW);
-      sa[q] = *reinterpret_cast<const unsigned char*>(sa_lane + slot * (BC * 4) + (j0 + q) * 64);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[j0 + q][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[q], fb[i], acc[j0 + q][i], 0, 0, 0, sa[q], 0, sb[i]);
-    // the pair's MFMAs stay in front of whatever memory operation follows (an MFMA is not a memory operation, so a plain
-    // memory clobber lets the compiler sink it below the next pair's LDS reads and the patch prefetch, whose 44 registers
-    // then no longer fit and spill one by one behind a full s_waitcnt)
-    asm volatile("" : "+v"(acc[j0][0]), "+v"(acc[j0][1]), "+v"(acc[j0][2]), "+v"(acc[j0][3]),
-                      "+v"(acc[j0 + 1][0]), "+v"(acc[j0 + 1][1]), "+v"(acc[j0 + 1][2]), "+v"(acc[j0 + 1][3]) :: "memory");
-  };
+  // one tap-step: B fragments (4 pixel rows) + the first weight fragment are read at the top -- the DMA issue of W[s+1] that
+  // follows covers their latency -- then weight fragment j+1 is read while the four MFMAs of fragment j run (two fragment
+  // registers sets of 8, ping-pong).  The asm fences keep every read in its slot and every MFMA row between its fences
+  // (an MFMA is not a memory operation: without the accumulator operands the compiler sinks MFMAs below later reads).
+#define F8_FENCE(j) asm volatile("" : "+v"(acc[j][0]), "+v"(acc[j][1]), "+v"(acc[j][2]), "+v"(acc[j][3]) :: "memory")
   auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps_of(c_)) { t_ = 0; ++c_; } };
   auto patch_row = [&](int vcb_, int tap_) {
     const unsigned code = tap_code(vcb_, tap_);
@@ -1571,14 +1549,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
   load_patch(0);
   int cb = 0, tap = 0, cbw = 0, tapw = 0;
   dma_w(0, 0, 0);
-  adv(cbw, tapw);
-  if (nsteps > 1) dma_w(cbw, tapw, 1);
-  adv(cbw, tapw);                    // -> W[2]
+  adv(cbw, tapw);                    // -> W[1], issued at the top of step 0
   store_patch();
   barrier_all();
-  int prow = patch_row(0, 0);
-  int pa = 0;
-  read_b(fb_lane + prow * PITCH, prow);
   for (int s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
     int ntap = tap + 1, ncbn = cb;
@@ -1586,38 +1559,55 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
     if (ntap == ntaps_cb) { ntap = 0; ncbn = cb + 1; }
     const bool swap = ntap == 0 && more;
     const bool patch_now = cb + 1 < ncb && (ntaps_cb == 1 || tap == 0);     // fetch the next block's patch during its predecessor's first step
-    const bool fetch = s + 2 < nsteps;
-    // (the empty asm with a memory clobber keeps the LDS reads of a pair behind the MFMAs of the previous pair also at IR
-    // level: hoisted together they need 32 more registers and the patch prefetch spills)
-    mma_pair(pa, s & 1, 0);
-    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-    mma_pair(pa, s & 1, 2);
-    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-    if (patch_now) load_patch(cb + 1);
-    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-    mma_pair(pa, s & 1, 4);
-    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-    mma_pair(pa, s & 1, 6);
-    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-    // every wave has read all it needs of this step: the barrier frees slot s&1 (and, at a block end, the patch); W[s+1] has landed
-    if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
-    pa = ((s + 1) & 1) * (BC * WROW);
-    prow = patch_row(ncbn < ncb ? ncbn : 0, ntap);
-    if (swap) {                      // channel-block boundary: the single-buffered patch is rewritten, then published
-      store_patch();
-      barrier_all();
+    const int slot = s & 1, pa = slot * (BC * WROW);
+    const int prow = patch_row(cb, tap);
+    const char* const pb = fb_lane + prow * PITCH;
+    const char* const sap = sa_lane + slot * (BC * 4);
+    i32x8_t fb[4], fa[2];
+    int sb[4], sa[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fb[i] = ld32(pb + i * PW * PITCH, pb + i * PW * PITCH + 64);
+      sb[i] = *reinterpret_cast<const unsigned char*>(sb_lane + (prow + i * PW) * 4);
     }
-    if (more) read_b(fb_lane + prow * PITCH, prow);
-    __builtin_amdgcn_sched_barrier(0);
-    if (fetch) { dma_setup(cbw, tapw, s & 1);
+    fa[0] = ld32(fa_k[0] + pa, fa_k[1] + pa);
+    sa[0] = *reinterpret_cast<const unsigned char*>(sap);
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    if (more) {                      // W[s+1] -> the other slot (free since the barrier that ended step s-1)
+      dma_setup(cbw, tapw, slot ^ 1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) dma_piece(q);
       dma_scales();
     }
     adv(cbw, tapw);
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    // the next block's patch goes out behind the DMA pieces (the barrier's counted wait then leaves it in flight) and before
+    // the MFMA rows: here only the B fragments and one weight fragment are live beside the prefetch registers
+    if (patch_now) {
+      load_patch(cb + 1);
+      asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < 7) {
+        fa[(j + 1) & 1] = ld32(fa_k[0] + pa + (j + 1) * 16 * WROW, fa_k[1] + pa + (j + 1) * 16 * WROW);
+        sa[(j + 1) & 1] = *reinterpret_cast<const unsigned char*>(sap + (j + 1) * 64);
+      }
+      F8_FENCE(j); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[j & 1], fb[i], acc[j][i], 0, 0, 0, sa[j & 1], 0, sb[i]);
+      F8_FENCE(j); __builtin_amdgcn_sched_barrier(0);
+    }
+    // every wave has read all it needs of this step: the barrier frees slot s&1 (and, at a block end, the patch); W[s+1] has landed
+    if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
+    if (swap) {                      // channel-block boundary: the single-buffered patch is rewritten, then published
+      store_patch();
+      barrier_all();
+    }
     tap = ntap; cb = ncbn;
   }
+#undef F8_FENCE
   halo_epilogue<bf16_t, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
 }
 
