@@ -1292,10 +1292,22 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
     const bool fetch = s + 2 < nsteps;
     // k-block 0 (fragments read at the end of the previous step), then k-block 1: after it every wave has read all it
     // needs of this step, so the barrier below frees slot s&1 (and, at a block end, the patch); W[s+1] has landed by then
+    // k-block 0, and the weight fragments of k-block 1 re-read row pair by row pair right behind the MFMAs that consumed their
+    // k-block-0 contents (that latency hides under the remaining rows; only the four pixel fragments are read in the open at
+    // the end): +0.5-1.5 % per launch against reading all twelve fragments after the block (the chip gives about half of a
+    // cycle saving back as clock).  The asm fences keep each read in its slot and each MFMA pair in front of it.
 #pragma unroll
-    for (int q = 0; q < 4; ++q) mma_rows(fa, fb, 2 * q);
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(fa, fb, pa, pb, 1);
+    for (int q = 0; q < 4; ++q) {
+      mma_rows(fa, fb, 2 * q);
+      asm volatile("" : "+v"(acc[2 * q][0]), "+v"(acc[2 * q][1]), "+v"(acc[2 * q][2]), "+v"(acc[2 * q][3]),
+                        "+v"(acc[2 * q + 1][0]), "+v"(acc[2 * q + 1][1]), "+v"(acc[2 * q + 1][2]), "+v"(acc[2 * q + 1][3]) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      fa[2 * q] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q) * 16 * WROW);
+      fa[2 * q + 1] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q + 1) * 16 * WROW);
+      asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + 64);
     __builtin_amdgcn_sched_barrier(0);
     if (patch_now) load_patch(cb + 1);
     __builtin_amdgcn_sched_barrier(0);
