@@ -439,7 +439,10 @@ extern "C" int dg_cast(int dtype, const float* src, void* dst, int64_t n, void* 
   return dg_check_launch();
 }
 
-// master [CoutP][9][CinP] fp32 -> kind 0: same layout in dtype; kind 1: [CinP][9][CoutP] (data-gradient pack)
+// master [CoutP][9][CinP] fp32 -> kind 0: same layout in dtype; kind 1: [CinP][9][CoutP] (data-gradient pack); kind 2: the
+// same with the taps MIRRORED (tap t of dst = tap 8 - t of master): the weights with which the data gradient of a stride-1 conv
+// is the plain FORWARD conv of dy (dx(p) = sum_t' dy(p + t') W[.][8 - t'][.]) -- used to run the data gradient of a layer with
+// <= 2 real output channels (generator conv3.2) on the im2col forward kernel
 template <typename T>
 __global__ void repack_kernel(const float* master, T* dst, int CoutP, int CinP, int kind) {
   const long long total = (long long)CoutP * 9 * CinP;
@@ -447,11 +450,26 @@ __global__ void repack_kernel(const float* master, T* dst, int CoutP, int CinP, 
     if (kind == 0) { st_elem(dst + i, master[i]); continue; }
     const int co = (int)(i % CoutP); const long long t = i / CoutP;
     const int tap = (int)(t % 9), ci = (int)(t / 9);
-    st_elem(dst + i, master[((long long)co * 9 + tap) * CinP + ci]);
+    st_elem(dst + i, master[((long long)co * 9 + (kind == 2 ? 8 - tap : tap)) * CinP + ci]);
   }
 }
+// dw[co][t][ci] += tmp[ci][8 - t][co]: folds the result of a weight-gradient launch with swapped operand roles (see
+// dg_repack_conv_weights kind 2 and engine.NativeGenerator.backward) back into the layer's own gradient layout
+__global__ void wgrad_unswap_kernel(const float* tmp, float* dw, int CoutP, int CinP) {
+  const int total = CoutP * 9 * CinP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ci = i % CinP, t = (i / CinP) % 9, co = i / (CinP * 9);
+    dw[i] += tmp[((long long)ci * 9 + (8 - t)) * CoutP + co];
+  }
+}
+extern "C" int dg_wgrad_unswap(const float* tmp, float* dw, int CoutP, int CinP, void* stream) {
+  if (!tmp || !dw || CoutP <= 0 || CinP <= 0) return DG_ERR_BAD_ARG;
+  const int total = CoutP * 9 * CinP;
+  hipLaunchKernelGGL(wgrad_unswap_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tmp, dw, CoutP, CinP);
+  return dg_check_launch();
+}
 extern "C" int dg_repack_conv_weights(int dtype, int kind, const float* master, void* dst, int CoutP, int CinP, void* stream) {
-  if (!master || !dst || CoutP <= 0 || CinP <= 0 || (kind != 0 && kind != 1)) return DG_ERR_BAD_ARG;
+  if (!master || !dst || CoutP <= 0 || CinP <= 0 || kind < 0 || kind > 2) return DG_ERR_BAD_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const unsigned nb = ew_blocks((long long)CoutP * 9 * CinP);
   if (dtype == DG_F32) hipLaunchKernelGGL(repack_kernel<float>, dim3(nb), dim3(256), 0, st, master, (float*)dst, CoutP, CinP, kind);

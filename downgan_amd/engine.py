@@ -395,6 +395,10 @@ class NativeGenerator:
         hs = S << num_upsample
         self.cv_c30 = Conv(B, hs, hs, F_, F_)
         self.cv_c32 = Conv(B, hs, hs, F_, self.np_p, cout_alg=n_predictands)
+        # conv3.2 has <= 2 real OUTPUT channels: its backward is HBM-bound and runs on the first-layer (im2col) kernels with the
+        # operand roles swapped -- data gradient = forward conv of dfake with the mirrored-tap pack, weight gradient =
+        # wgrad(x := dfake, dy := c30) folded back by wgrad_unswap (dg_repack_conv_weights kind 2 / dg_wgrad_unswap)
+        self.cv_c32_bwd = Conv(B, hs, hs, self.np_p, F_, cin_real=n_predictands, cin_alg=n_predictands) if n_predictands <= 2 else None
         P = self.P = ParamStore(ops)
 
         def addconv(name, cv, dgrad=True):
@@ -428,6 +432,10 @@ class NativeGenerator:
         # backward never reads them); conv k's epilogue writes its slice of it, the next conv reads the first k+1 slices.
         self.f8 = bool(getattr(o, "f8_generator", False)) and all(o.f8_eligible(cv, "fwd") for cv in self.cv_b)
         self._qring = [(o.zeros(B, S, S, 5 * F_, dtype=torch.uint8), o.zeros(B, S, S, 5 * F_ // 32, dtype=torch.uint8)) for _ in range(4)] if self.f8 else None
+        self._w_c32_bwd = o.zeros(F_ * 9 * self.np_p) if self.cv_c32_bwd is not None else None
+        self._dw_c32_tmp = None
+        if self.cv_c32_bwd is not None:
+            P.after_refresh.append(lambda: o.repack(P.master("conv3.2.weight").reshape(-1), self._w_c32_bwd, self.np_p, F_, 2))
         self._wq = {}
         self._qlast = None
         if self.f8:
@@ -553,8 +561,17 @@ class NativeGenerator:
         GW = lambda n: P.grad(n + ".weight").reshape(-1)
         GB = lambda n: P.grad(n + ".bias")
         # conv3.2 / conv3.0
-        o.conv_wgrad(self.cv_c32, self.c30, dfake, GW("conv3.2"), db=GB("conv3.2"))
-        o.conv_dgrad(self.cv_c32, dfake, WD("conv3.2"), bw["d_c30"], mask=self.c30, mask_slope=G_SLOPE)
+        if self.cv_c32_bwd is not None:
+            if self._dw_c32_tmp is None:
+                self._dw_c32_tmp = o.zeros(F_ * 9 * self.np_p, dtype=torch.float32)
+            self._dw_c32_tmp.zero_()
+            o.conv_wgrad(self.cv_c32_bwd, dfake, self.c30, self._dw_c32_tmp)          # roles swapped: [ci][8 - t][co]
+            o.wgrad_unswap(self._dw_c32_tmp, GW("conv3.2"), self.np_p, F_)
+            o.colsum(dfake, GB("conv3.2"))
+            o.conv_fwd(self.cv_c32_bwd, dfake, self._w_c32_bwd, bw["d_c30"], mask=self.c30, mask_slope=G_SLOPE)
+        else:
+            o.conv_wgrad(self.cv_c32, self.c30, dfake, GW("conv3.2"), db=GB("conv3.2"))
+            o.conv_dgrad(self.cv_c32, dfake, WD("conv3.2"), bw["d_c30"], mask=self.c30, mask_slope=G_SLOPE)
         top = self.ups[-1] if self.nup else self.trunk
         o.conv_wgrad(self.cv_c30, top, bw["d_c30"], GW("conv3.0"), db=GB("conv3.0"))
         dcur = bw["d_ups"][-1] if self.nup else bw["d_trunk"]

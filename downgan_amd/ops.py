@@ -318,6 +318,11 @@ class HipOps:
         assert dst.dtype == self.tdtype and dst.numel() == cout * 9 * cin
         check(self.lib.dg_repack_conv_weights(self.dg, kind, _ptr(master), _ptr(dst), cout, cin, self._stream()), "dg_repack_conv_weights")
 
+    def wgrad_unswap(self, tmp, dw, cout, cin):
+        """dw[co][t][ci] += tmp[ci][8 - t][co] (both fp32 flat): see dg_wgrad_unswap."""
+        assert tmp.dtype == torch.float32 and dw.dtype == torch.float32 and tmp.numel() == dw.numel() == cout * 9 * cin
+        check(self.lib.dg_wgrad_unswap(_ptr(tmp), _ptr(dw), cout, cin, self._stream()), "dg_wgrad_unswap")
+
     # ------------------------------------------------------------------ linear family
     def linear_fwd(self, x, w, y, o_real=0, net=""):
         """y[B,ldy] (fp32, pre-zeroed) += x[B,K] @ w[O,K]^T"""

@@ -157,6 +157,11 @@ int dg_conv3x3_plan(const dg_conv_geom* g, int kind, dg_gg_desc* out);
  *   kind 0 (forward pack): same layout cast to `dtype`;  kind 1 (dgrad pack): dst[ci][tap][co]. */
 int dg_repack_conv_weights(int dtype, int kind, const float* master, void* dst, int CoutP, int CinP,
                            void* stream);
+/* Two helpers for layers with <= 2 real OUTPUT channels (generator conv3.2, generator.py:80), whose backward is HBM-bound:
+ * dg_repack_conv_weights kind 2 = kind 1 with mirrored taps, the pack with which that layer's data gradient is a forward conv of
+ * dy over its 2 real channels (im2col kernel); dg_wgrad_unswap: dw[co][t][ci] += tmp[ci][8-t][co], which folds a weight-gradient
+ * launch with swapped operand roles (x := dy with 2 real channels, dy := x) back into the layer's gradient layout. */
+int dg_wgrad_unswap(const float* tmp, float* dw, int CoutP, int CinP, void* stream);
 
 /* ---- Linear family (replaces nn.Linear in critic.py:94-105) ---------------------------------- */
 

@@ -229,8 +229,13 @@ class EmuOps:
         m = master.view(cout, 9, cin)
         if kind == 0:
             dst.copy_(m.reshape(-1).to(dst.dtype))
-        else:
+        elif kind == 1:
             dst.copy_(m.permute(2, 1, 0).reshape(-1).to(dst.dtype))
+        else:                                    # kind 2: data-gradient pack with mirrored taps
+            dst.copy_(m.permute(2, 1, 0).flip(1).reshape(-1).to(dst.dtype))
+
+    def wgrad_unswap(self, tmp, dw, cout, cin):
+        dw.view(cout, 9, cin).add_(tmp.view(cin, 9, cout).flip(1).permute(2, 1, 0))
 
     # ------------------------------------------------------------------ linear family
     def linear_fwd(self, x, w, y, o_real=0, net=""):

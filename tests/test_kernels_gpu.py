@@ -406,3 +406,43 @@ def test_previous_generation_halo_kernels_in_a_subprocess():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "previous-generation kernels ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_small_cout_backward_on_first_layer_kernels(dtype):
+    """A stride-1 layer with <= 2 real OUTPUT channels (generator conv3.2, generator.py:80): its data gradient as the forward conv
+    of dy with the mirrored-tap pack (dg_repack_conv_weights kind 2 -> im2col forward kernel, with the LeakyReLU' mask epilogue),
+    its weight gradient as the swapped-role launch folded back by dg_wgrad_unswap -- both against the ordinary paths' oracle."""
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(9)
+    N, H, W, F_, npad, nreal = 2, 32, 64, 128, 16, 2
+    cv = Conv(N, H, W, F_, npad, 1, False)                     # the layer as it is: 128 -> 16 (2 real)
+    cvb = Conv(N, H, W, npad, F_, 1, False, cin_real=nreal)    # its backward as a first-layer-shaped conv
+    master = torch.zeros(npad, 9, F_)
+    master[:nreal] = torch.randn(nreal, 9, F_, generator=g) * 0.1
+    dy = torch.zeros(N, H, W, npad)
+    dy[..., :nreal] = torch.randn(N, H, W, nreal, generator=g)
+    dy = dy.to(emu.tdtype)
+    x = rnd((N, H, W, F_), emu.tdtype, g)
+    mask = rnd((N, H, W, F_), emu.tdtype, g)
+    # reference: ordinary data gradient / weight gradient through the oracle ops
+    wd = torch.zeros(npad * 9 * F_, dtype=emu.tdtype)
+    emu.repack(master.reshape(-1), wd, npad, F_, 1)
+    dx_ref = torch.zeros(N, H, W, F_, dtype=emu.tdtype)
+    emu.conv_dgrad(cv, dy, wd, dx_ref, mask=mask, mask_slope=0.01)
+    dw_ref = torch.zeros(npad * 9 * F_)
+    emu.conv_wgrad(cv, x, dy, dw_ref)
+    # native: mirrored pack + forward kernel; swapped wgrad + unswap
+    wm = torch.zeros(npad * 9 * F_, dtype=emu.tdtype).cuda()
+    hip.repack(master.reshape(-1).cuda(), wm, npad, F_, 2)
+    dx = torch.zeros(N, H, W, F_, dtype=emu.tdtype).cuda()
+    hip.conv_fwd(cvb, dy.cuda(), wm, dx, mask=mask.cuda(), mask_slope=0.01)
+    assert hip.lib.dg_last_conv_kernels() == 16                 # im2col kernel
+    close(dx, dx_ref, dtype, "conv3.2 dgrad as forward")
+    tmp = torch.zeros(npad * 9 * F_).cuda()
+    hip.conv_wgrad(cvb, dy.cuda(), x.cuda(), tmp)
+    dw = torch.zeros(npad * 9 * F_).cuda()
+    hip.wgrad_unswap(tmp, dw, npad, F_)
+    a, b = dw.cpu(), dw_ref
+    tol = 1e-5 if dtype == "f32" else 1e-4
+    assert (a - b).abs().max().item() <= tol * 8 * float(b.abs().max()), (a - b).abs().max().item()
