@@ -122,3 +122,33 @@ def test_epoch_loop_checkpoints_both_networks(monkeypatch, tmp_path):
         load_state_dict(fresh, str(path))
         a, b = net.state_dict(), fresh.state_dict()
         assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_ragged_last_batch_rebinds_the_engine(monkeypatch):
+    """A DataLoader's ragged last batch (the reference's own _gp cannot take it: wasserstein.py:110 reshapes with hp.batch_size):
+    the mirror re-creates its shape-bound engine for the new batch size and carries the CURRENT parameters over."""
+    from downgan_amd import backend, synthetic
+    from downgan_amd.GAN import losses
+    from downgan_amd.GAN.dataloader import NetCDFSR
+    from downgan_amd.GAN.wasserstein import WassersteinGAN
+    from downgan_amd.networks.critic import Critic
+    from downgan_amd.networks.generator import Generator
+    from oracle.emu_ops import EmuOps
+    import downgan_amd.config.hyperparams as hp
+    monkeypatch.setattr(backend, "make_ops", lambda dtype, device: EmuOps("f32"))
+    monkeypatch.setattr(losses, "_ops", {})
+    monkeypatch.setattr(hp, "batch_size", 2)
+    torch.set_num_threads(4)
+    coarse, fine = synthetic.tiles(3, 2, 16, seed=6)
+    G, C = Generator(16, 128, 2, 2, num_res_blocks=1), Critic(16, 128, 2)
+    tr = WassersteinGAN(G, C)
+    tr.log_metrics = False
+    dl = torch.utils.data.DataLoader(NetCDFSR(torch.from_numpy(coarse), torch.from_numpy(fine)), batch_size=2)
+    (log,) = tr.train(dl, None, epochs=1)
+    assert len(log) == 2 and tr._engine.B == 1 and tr.num_steps == 2
+    import math
+    assert math.isfinite(log[0]["critic_loss"]) and math.isfinite(log[1]["critic_loss"])
+    # two critic updates reached the mirror's parameters: both engines (B = 2, then B = 1) worked on the same network
+    sd0, sd1 = Critic(16, 128, 2).state_dict(), C.state_dict()
+    moved = max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0)
+    assert 1.5 * hp.lr < moved <= 2.0 * hp.lr * 1.01, moved        # Adam moves an entry by at most lr per step: > 1.5 lr needs both steps
