@@ -75,6 +75,7 @@ _PROTOS = {
     "dg_linear_fwd": [_i, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i64, _vp],
     "dg_linear_dx": [_i, _i, _vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _f, _i, _i, _i64, _vp],
     "dg_linear_dw": [_i, _vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i64, _vp],
+    "dg_linear_dw_wide": [_i, _vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i64, _i, _vp],
     "dg_bias_act": [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _f, _vp],
     "dg_mask_mul": [_i, _vp, _i64, _vp, _i64, _i64, _i, _f, _vp],
     "dg_axpby": [_i, _vp, _i64, _vp, _i64, _f, _vp, _i64, _f, _i64, _i, _vp],

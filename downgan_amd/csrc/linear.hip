@@ -273,3 +273,119 @@ extern "C" int dg_linear_dw(int dtype, const float* dy, int ldo, const void* x, 
     return DG_ERR_BAD_DTYPE;
   return dg_check_launch();
 }
+
+// ---- FC1 weight gradient, all passes of a critic iteration in ONE sweep over the 1.9 GB fp32 gradient -------------------------
+// dw[o][k] (=|+=) sum_b dy[b][o] x[b][k] for B <= 128 rows (the real, fake and penalty-tangent rows of wasserstein.py:52
+// concatenated), O <= 112.  lin_dw_kernel re-reads x once per 16-row tile of o and read-modify-writes dw once per call (three
+// calls per critic iteration: 3.5 ms per step at cfg2; this sweep: 1.1 ms).  A workgroup of 8 waves owns 256 consecutive k of
+// ALL 112 gradient rows: wave w holds rows [14w, 14w+14) x 4 k per lane = 56 accumulators as float2 pairs (v_pk_fma_f32: 2 FMAs
+// per VALU slot; the sweep is ~45 G FMA at cfg2, comparable to its memory time); the adjoint values are wave-uniform and come
+// by SCALAR loads (SGPR operands of the packed FMAs: no LDS, no barrier); x is loaded once per wave through a buffer descriptor
+// based at the row (the waves of a workgroup hit L1/L2 for the same 1-KB runs), one register set ahead of its arithmetic.
+// `accumulate == 0` writes the result: neither the gradient zero-fill nor the read of dw is needed.
+typedef __attribute__((ext_vector_type(2))) float dg_f32x2_t;
+template <typename T> struct LdX4;
+// one row's 4 elements per lane through a buffer descriptor based at the (workgroup-uniform) row: scalar base + 32-bit lane
+// offset.  Written as pointer arithmetic the compiler hoists `x + k` into a 64-bit VGPR pair per lane and serialises the loads.
+typedef __attribute__((ext_vector_type(2))) unsigned int dg_u32x2_t;
+template <> struct LdX4<float> {
+  typedef dg_u32x4_t raw;
+  static __device__ __forceinline__ raw load(const float* row, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)row, 0, -1, 0x00020000), voff, 0, 0);
+  }
+  static __device__ __forceinline__ void cvt(const raw& t, dg_f32x2_t& a, dg_f32x2_t& b) {
+    a = dg_f32x2_t{__uint_as_float(t[0]), __uint_as_float(t[1])}; b = dg_f32x2_t{__uint_as_float(t[2]), __uint_as_float(t[3])};
+  }
+};
+template <> struct LdX4<bf16_t> {
+  typedef dg_u32x2_t raw;
+  static __device__ __forceinline__ raw load(const bf16_t* row, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(__builtin_amdgcn_make_buffer_rsrc((void*)row, 0, -1, 0x00020000), voff, 0, 0);
+  }
+  static __device__ __forceinline__ void cvt(const raw& t, dg_f32x2_t& a, dg_f32x2_t& b) {
+    a = dg_f32x2_t{__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u)};
+    b = dg_f32x2_t{__uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
+  }
+};
+
+template <typename T, bool ACC, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void lin_dw_wide_kernel(const float* __restrict__ dy, int ldo, const T* __restrict__ x,
+                                                                  long long ldx, float* dw, long long lddw, int B, int O,
+                                                                  long long K, int cpw) {
+  constexpr int OW = 112 / NWV, UB = 4;              // gradient rows per wave (28 or 14), batch rows per register set
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* dyw = dy + wave * OW;                 // wave-uniform: the adjoint values arrive by scalar loads (ldo >= 112)
+  for (int c = 0; c < cpw; ++c) {
+    const long long k = (((long long)blockIdx.x * cpw + c) * 64 + lane) * 4;
+    if (k >= K) break;                               // K % 4 == 0; past-the-end lanes of the last chunk only
+    dg_f32x2_t acc[OW][2];
+#pragma unroll
+    for (int j = 0; j < OW; ++j) acc[j][0] = acc[j][1] = dg_f32x2_t{0.f, 0.f};
+    const unsigned voff = (unsigned)k * (unsigned)sizeof(T);   // a row is < 4 GB (checked by the launcher)
+    // two register sets of UB rows: the next set's loads are in flight while the current one feeds UB * OW * 2 packed FMAs
+    // (with the loads at the head of each set's own arithmetic the memory round trip was in the open: 2.3 ms per sweep)
+    typename LdX4<T>::raw xr[2][UB];
+    auto fetch = [&](int set, int b0) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {                 // past the last row: a harmless re-read of row B-1
+        const int b = b0 + u < B ? b0 + u : B - 1;
+        xr[set][u] = LdX4<T>::load(x + (long long)b * ldx, voff);
+      }
+    };
+    auto row_fma = [&](const typename LdX4<T>::raw& r, int b) {
+      const float* dp = dyw + (long long)b * ldo;
+      dg_f32x2_t xa, xb;
+      LdX4<T>::cvt(r, xa, xb);
+#pragma unroll
+      for (int j = 0; j < OW; ++j) {
+        const float dv = dp[j];
+        const dg_f32x2_t d2 = {dv, dv};
+        acc[j][0] = __builtin_elementwise_fma(d2, xa, acc[j][0]);
+        acc[j][1] = __builtin_elementwise_fma(d2, xb, acc[j][1]);
+      }
+    };
+    const int Bm = B / (2 * UB) * (2 * UB);
+    fetch(0, 0);
+    for (int b0 = 0; b0 < Bm; b0 += 2 * UB) {
+      fetch(1, b0 + UB);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) row_fma(xr[0][u], b0 + u);
+      fetch(0, b0 + 2 * UB);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) row_fma(xr[1][u], b0 + UB + u);
+    }
+    for (int b = Bm; b < B; ++b) row_fma(LdX4<T>::load(x + (long long)b * ldx, voff), b);     // < 8 leftover rows
+#pragma unroll
+    for (int j = 0; j < OW; ++j) {
+      const int o = wave * OW + j;
+      if (o >= O) break;
+      float4* p = reinterpret_cast<float4*>(dw + (long long)o * lddw + k);
+      float4 t = make_float4(acc[j][0][0], acc[j][0][1], acc[j][1][0], acc[j][1][1]);
+      if (ACC) {
+        const float4 old = *p;
+        t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w;
+      }
+      *p = t;
+    }
+  }
+}
+
+extern "C" int dg_linear_dw_wide(int dtype, const float* dy, int ldo, const void* x, int64_t ldx, float* dw, int64_t lddw,
+                                 int B, int O, int64_t K, int accumulate, void* stream) {
+  if (!dy || !x || !dw) return DG_ERR_BAD_ARG;
+  if (B <= 0 || B > 128 || O <= 0 || O > 112 || ldo < 112 || K <= 0 || K >= (1ll << 30) || K % 4 || ldx % 4 || lddw % 4 || ldx < K || lddw < K)
+    return DG_ERR_BAD_SHAPE;
+  if (dtype != DG_F32 && dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long chunks = (K + 255) / 256;
+  const int cpw = chunks >= 8 * 2048 ? 8 : chunks >= 2048 ? 2 : 1;      // >= 2048 workgroups (4 resident rounds of 2 per CU)
+  const unsigned grid = (unsigned)((chunks + cpw - 1) / cpw);
+  constexpr int NWV = 8;
+#define DG_LDW(T, ACC)                                                                                                  \
+  hipLaunchKernelGGL((lin_dw_wide_kernel<T, ACC, NWV>), dim3(grid), dim3(64 * NWV), 0, st, dy, ldo, (const T*)x, \
+                     (long long)ldx, dw, (long long)lddw, B, O, (long long)K, cpw)
+  if (dtype == DG_F32) { if (accumulate) DG_LDW(float, true); else DG_LDW(float, false); }
+  else { if (accumulate) DG_LDW(bf16_t, true); else DG_LDW(bf16_t, false); }
+#undef DG_LDW
+  return dg_check_launch();
+}

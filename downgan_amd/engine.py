@@ -133,9 +133,15 @@ class ParamStore:
         for fn in self.after_refresh:
             fn()
 
-    def zero_grad(self):
+    def zero_grad(self, skip=None):
+        """``skip``: an entry whose gradient the caller WRITES (not accumulates) later in the iteration."""
         self.sync()
-        self.g.zero_()
+        if skip is None:
+            self.g.zero_()
+        else:
+            off, n, _ = self.entries[skip]
+            self.g[:off].zero_()
+            self.g[off + n:].zero_()
 
     def adam_step(self, hp: HyperParams, grad_scale=1.0):
         self.t += 1
@@ -209,6 +215,14 @@ class NativeCritic:
         self.dout = o.zeros(batch, FC_OUT_P, dtype=torch.float32)
         self.uh1 = o.zeros(batch, FC_HID_LD, dtype=torch.float32)
         self._tan = None
+        # FC1's weight gradient (1.9 GB fp32 at cfg2) is formed ONCE per critic iteration from the rows of all three passes
+        # (dg_linear_dw_wide) instead of being read-modify-written by each: slots 0-2 of these buffers hold FC1's input rows
+        # (real activation, fake activation, penalty tangent) and the matching adjoint rows; slot 3 = passes without one.
+        self.fc1_fused = 3 * batch <= 128 and os.environ.get("DG_NO_FC1_FUSED") is None
+        if self.fc1_fused:
+            self._y7_all = o.zeros(4 * batch, *self.acts[7].shape[1:])
+            self._uh1_all = o.zeros(3 * batch, FC_HID_LD, dtype=torch.float32)
+            self.acts[7] = self._y7_all[3 * batch:]
         # fp8 mode (BASELINE configs[4]): MXFP8 forms of every tensor an fp8 conv reads -- activations act[l-1] (forward of
         # layer l), adjoints us[l] (data gradient of layer l), the penalty's tangents, both weight packs -- written by the
         # PRODUCING launch's epilogue (dg_epilogue.out_q) or, for the weights, once per optimizer step; None = not needed
@@ -275,9 +289,13 @@ class NativeCritic:
         return self.unpack(self.P.to_host(self.P.g))
 
     # ---- forward ------------------------------------------------------------------------------------
-    def forward(self, x):
-        """critic.py:101-106.  x: NHWC [B, fine, fine, c_pad[0]].  Returns out[:, 0] (fp32 view)."""
+    def forward(self, x, fc1_slot=None):
+        """critic.py:101-106.  x: NHWC [B, fine, fine, c_pad[0]].  Returns out[:, 0] (fp32 view).
+        ``fc1_slot``: keep FC1's input rows of this pass for the iteration's single FC1 weight-gradient sweep."""
         o, P = self.ops, self.P
+        if self.fc1_fused:
+            s = 3 if fc1_slot is None else fc1_slot
+            self.acts[7] = self._y7_all[s * self.B:(s + 1) * self.B]
         cur = x
         for l, cv in enumerate(self.convs):
             f8kw = dict(xq=self.actq[l - 1] if l else None, wq=self.wq_f[l], out_q=self.actq[l]) if self.f8 else {}
@@ -295,22 +313,25 @@ class NativeCritic:
         return self.out
 
     # ---- adjoint chain (backward of a forward just run on x) ---------------------------------------
-    def backward(self, x, dout_value, wgrad=True, dx=None):
+    def backward(self, x, dout_value, wgrad=True, dx=None, fc1_slot=None):
         """d(out_b)/d(.) * dout_value for every sample.  wgrad: accumulate parameter gradients
         (autograd backward of wasserstein.py:52); dx: if given, receives the input gradient
-        (wasserstein.py:100-106 / :80)."""
+        (wasserstein.py:100-106 / :80).  ``fc1_slot``: FC1's adjoint rows go to that slot and its weight gradient is left
+        to ``fc1_flush`` (the forward must have used the same slot)."""
         o, P = self.ops, self.P
+        uh1 = self.uh1 if fc1_slot is None else self._uh1_all[fc1_slot * self.B:(fc1_slot + 1) * self.B]
         self.dout.zero_()
         o.fill_col(self.dout, 0, dout_value)
         y7 = self.acts[7].view(self.B, self.fc_k)
         if wgrad:
             o.linear_dw(self.dout, self.h1, P.grad("classifier.2.weight"), o_real=1, net="C")
             o.colsum(self.dout, P.grad("classifier.2.bias"))
-        o.linear_dx(self.dout, P.w2d("classifier.2.weight"), self.uh1, mask=self.h1, mask_slope=C_SLOPE, o_real=1, net="C")
+        o.linear_dx(self.dout, P.w2d("classifier.2.weight"), uh1, mask=self.h1, mask_slope=C_SLOPE, o_real=1, net="C")
         if wgrad:
-            o.linear_dw(self.uh1[:, :FC_HID_P], y7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
-            o.colsum(self.uh1, P.grad("classifier.0.bias"))
-        o.linear_dx(self.uh1[:, :FC_HID_P], P.w2d("classifier.0.weight"), self.us[7].view(self.B, self.fc_k),
+            if fc1_slot is None:
+                o.linear_dw(uh1[:, :FC_HID_P], y7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
+            o.colsum(uh1, P.grad("classifier.0.bias"))
+        o.linear_dx(uh1[:, :FC_HID_P], P.w2d("classifier.0.weight"), self.us[7].view(self.B, self.fc_k),
                     mask=y7, mask_slope=C_SLOPE, o_real=FC_HID, net="C")
         if self.usq[7] is not None:       # the only adjoint that does not come out of a conv epilogue
             o.quant_mxfp8(self.us[7], *self.usq[7])
@@ -330,7 +351,13 @@ class NativeCritic:
                 o.conv_dgrad(cv, self.us[0], P.wd(name), dx)
 
     # ---- gradient penalty: forward, adjoint, norm, tangent forward + weight gradients -------------
-    def gp_pass(self, xhat, g_buf, v_buf, ss, coef, gp_scalar, hp: HyperParams, b_global):
+    def fc1_flush(self, accumulate=False):
+        """The FC1 weight gradient of the passes parked in slots 0-2 (real, fake, penalty tangent): one sweep."""
+        n = 3 * self.B
+        self.ops.linear_dw_wide(self._uh1_all[:, :FC_HID_P], self._y7_all[:n].view(n, self.fc_k),
+                                self.P.grad("classifier.0.weight"), accumulate=accumulate, o_real=FC_HID, net="C")
+
+    def gp_pass(self, xhat, g_buf, v_buf, ss, coef, gp_scalar, hp: HyperParams, b_global, fc1_slot=None):
         """wasserstein.py:87-117 and its contribution to critic_loss.backward (:52).
 
         g = d sum_b C(xhat_b) / d xhat (adjoint chain with grad_outputs = 1).  With piecewise-linear
@@ -338,7 +365,7 @@ class NativeCritic:
         the tangent is v0 = dGP/dg pushed forward through the same masked linear maps."""
         o, P = self.ops, self.P
         self.forward(xhat)
-        self.backward(xhat, 1.0, wgrad=False, dx=g_buf)
+        self.backward(xhat, 1.0, wgrad=False, dx=g_buf, fc1_slot=fc1_slot)
         ss.zero_()
         o.sumsq_rows(g_buf, ss)
         o.gp_finish(ss, self.B, b_global, hp.gp_lambda, hp.gp_lambda, coef, gp_scalar)
@@ -357,6 +384,8 @@ class NativeCritic:
             name = f"features.{2 * l}.weight"
             o.conv_wgrad(cv, t, self.us[l], P.grad(name).reshape(-1))
             tn = self._tan[l & 1][:self.acts[l].numel()].view(self.acts[l].shape)
+            if l == 7 and fc1_slot is not None:           # FC1's tangent input rows stay for fc1_flush
+                tn = self._y7_all[fc1_slot * self.B:(fc1_slot + 1) * self.B]
             f8kw, tqn = {}, None
             if self.f8:
                 if self.actq[l] is not None:          # the next layer's tangent forward is an fp8 conv
@@ -369,7 +398,8 @@ class NativeCritic:
                 o.conv_fwd(cv, t, P.w(name), tn, mask=self.acts[l], mask_slope=C_SLOPE, **f8kw)
             t, tq = tn, tqn
         t7 = t.view(self.B, self.fc_k)
-        o.linear_dw(self.uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
+        if fc1_slot is None:
+            o.linear_dw(self.uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
         self._th1pre.zero_()
         o.linear_fwd(t7, P.w2d("classifier.0.weight"), self._th1pre, o_real=FC_HID, net="C")
         o.bias_act(self._th1pre, None, self._th1, mask=self.h1, mask_slope=C_SLOPE)
@@ -701,17 +731,20 @@ class TrainEngine:
         real_first = self.G.P._pending is not None
         if not real_first:
             fake = self.G.forward(coarse, save=save_g)            # :35
-        C.P.zero_grad()                                           # :43
-        out = C.forward(fine)                                     # :37
+        s0, s1, s2 = (0, 1, 2) if C.fc1_fused else (None, None, None)
+        C.P.zero_grad(skip="classifier.0.weight" if C.fc1_fused else None)    # :43 (fc1_flush WRITES that gradient)
+        out = C.forward(fine, s0)                                 # :37
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
-        C.backward(fine, -1.0 / bg)                               # d(-mean c_real)
+        C.backward(fine, -1.0 / bg, fc1_slot=s0)                  # d(-mean c_real)
         if real_first:
             fake = self.G.forward(coarse, save=save_g)            # :35 (first use of G's parameters completes their update)
-        out = C.forward(fake)                                     # :38
+        out = C.forward(fake, s1)                                 # :38
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
-        C.backward(fake, 1.0 / bg)                                # d(+mean c_fake)
+        C.backward(fake, 1.0 / bg, fc1_slot=s1)                   # d(+mean c_fake)
         o.gp_interp(fine, fake, alpha, self.xhat)                 # :94
-        C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg)   # :40,:87-117
+        C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, fc1_slot=s2)   # :40,:87-117
+        if C.fc1_fused:
+            C.fc1_flush()
         if apply_update:
             self._allreduce_and_step(C.P, defer=True)             # :52-55 (overlaps with the next generator forward)
 
@@ -853,15 +886,18 @@ class TrainEngineFS(TrainEngine):
         fake = self.G.forward(coarse, save=save_g)                # :36
         o.lowpass5(fake, high=self.fake_high)                     # :37,40
         o.lowpass5(fine, high=self.real_high)                     # :38,41
-        C.P.zero_grad()                                           # :49
-        out = C.forward(self.real_high)                           # :43
+        s0, s1, s2 = (0, 1, 2) if C.fc1_fused else (None, None, None)
+        C.P.zero_grad(skip="classifier.0.weight" if C.fc1_fused else None)    # :49 (fc1_flush WRITES that gradient)
+        out = C.forward(self.real_high, s0)                       # :43
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
-        C.backward(self.real_high, -1.0 / bg)
-        out = C.forward(self.fake_high)                           # :44
+        C.backward(self.real_high, -1.0 / bg, fc1_slot=s0)
+        out = C.forward(self.fake_high, s1)                       # :44
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
-        C.backward(self.fake_high, 1.0 / bg)
+        C.backward(self.fake_high, 1.0 / bg, fc1_slot=s1)
         o.gp_interp(self.real_high, self.fake_high, alpha, self.xhat)          # :46 -> _gp(real_high, fake_high)
-        C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg)
+        C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, fc1_slot=s2)
+        if C.fc1_fused:
+            C.fc1_flush()
         if apply_update:
             self._allreduce_and_step(C.P, defer=True)             # :57-60
 

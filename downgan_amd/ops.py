@@ -361,6 +361,17 @@ class HipOps:
             self.dg, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dw.stride(0), B, O, K, self._stream()),
             float(x.element_size() * B * K + 8.0 * O * K), net), "dg_linear_dw")
 
+    def linear_dw_wide(self, dy, x, dw, accumulate=True, o_real=0, net=""):
+        """dw[O,K] (fp32) (+)= dy[B,O]^T @ x[B,K] for B <= 128 concatenated rows, O <= 112: one sweep over dw."""
+        self._act(x)
+        B, K = x.shape
+        O = dw.shape[0]
+        assert dy.dtype == torch.float32 and dy.shape[0] == B and dy.shape[1] >= O and dw.dtype == torch.float32 and dw.shape[1] == K
+        assert B <= 128 and O <= 112 and x.stride(1) == 1 and dw.stride(1) == 1 and dy.stride(1) == 1
+        check(self._timed("lin_dw", 2.0 * B * (o_real or O) * K, lambda: self.lib.dg_linear_dw_wide(
+            self.dg, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dw.stride(0), B, O, K, int(bool(accumulate)),
+            self._stream()), float(x.element_size() * B * K + (8.0 if accumulate else 4.0) * O * K), net), "dg_linear_dw_wide")
+
     def bias_act(self, inp, bias, out, act=None, mask=None, mask_slope=1.0):
         rows, Cc = out.shape
         assert inp.dtype == torch.float32 and inp.shape[0] == rows and inp.shape[1] >= Cc

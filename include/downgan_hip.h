@@ -176,6 +176,12 @@ int dg_linear_dx(int dtype, int out_dtype, const float* dy, int ldo, const void*
 /* dw[o][k] (fp32) += sum_b dy[b][o] * x[b][k]. */
 int dg_linear_dw(int dtype, const float* dy, int ldo, const void* x, int64_t ldx, float* dw,
                  int64_t lddw, int B, int O, int64_t K, void* stream);
+/* The same product for up to 128 rows and O <= 112 in ONE sweep over dw: the rows of every pass that contributes to
+ * critic_loss.backward() (wasserstein.py:52: real, fake, penalty tangent) concatenated, so the 1.9 GB FC1 gradient
+ * (critic.py:94-96) is written once per iteration instead of read-modify-written once per pass.
+ * accumulate != 0: dw += ...; accumulate == 0: dw = ... (no zero-fill needed).  K % 4 == 0. */
+int dg_linear_dw_wide(int dtype, const float* dy, int ldo, const void* x, int64_t ldx, float* dw,
+                      int64_t lddw, int B, int O, int64_t K, int accumulate, void* stream);
 
 /* ---- elementwise / reductions ----------------------------------------------------------------- */
 

@@ -253,6 +253,14 @@ class EmuOps:
         O = dw.shape[0]
         dw += dy[:, :O].t() @ x.float()
 
+    def linear_dw_wide(self, dy, x, dw, accumulate=True, o_real=0, net=""):
+        O = dw.shape[0]
+        r = dy[:, :O].t() @ x.float()
+        if accumulate:
+            dw += r
+        else:
+            dw.copy_(r)
+
     def bias_act(self, inp, bias, out, act=None, mask=None, mask_slope=1.0):
         Cc = out.shape[1]
         v = inp[:, :Cc].clone()

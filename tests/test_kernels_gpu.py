@@ -181,6 +181,35 @@ def test_linear(dtype, B, K, O):
         emu.linear_dw(dy, x, dw_ref)
         hip.linear_dw(dy.cuda(), x.cuda(), dw)
         close(dw, dw_ref, "f32", "linear_dw")
+    if B <= 128 and O <= 112:           # the single-sweep form: accumulate and write modes, padded row strides
+        for acc in (True, False):
+            dw_ref = torch.randn(O, K, generator=g)
+            dw = dw_ref.clone().cuda()
+            emu.linear_dw_wide(dy, x, dw_ref, accumulate=acc)
+            hip.linear_dw_wide(dy.cuda(), x.cuda(), dw, accumulate=acc)
+            close(dw, dw_ref, "f32", f"linear_dw_wide acc={acc}")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_linear_dw_wide_three_passes(dtype):
+    """96 concatenated rows (three passes of batch 32) x 100 real outputs in a 112-row gradient, K with a ragged last
+    256-chunk: equals three accumulating dg_linear_dw calls (what the engine did per pass)."""
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(77)
+    B, O, K = 96, 112, 256 * 37 + 136
+    x = rnd((B, K), emu.tdtype, g)
+    dy = torch.zeros(B, 128)
+    dy[:, :100] = torch.randn(B, 100, generator=g)
+    ref = torch.zeros(O, K)
+    for p in range(3):
+        emu.linear_dw(dy[32 * p:32 * p + 32], x[32 * p:32 * p + 32], ref)
+    dw = torch.full((O, K), float("nan")).cuda()          # write mode must not read the destination
+    hip.linear_dw_wide(dy.cuda()[:, :O], x.cuda(), dw, accumulate=False)
+    close(dw, ref, "f32", "linear_dw_wide 3x32")
+    three = torch.zeros(O, K).cuda()
+    for p in range(3):
+        hip.linear_dw(dy.cuda()[32 * p:32 * p + 32], x.cuda()[32 * p:32 * p + 32], three)
+    close(dw, three, "f32", "linear_dw_wide vs 3 x linear_dw")
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -211,5 +211,7 @@ def test_hip_graph_replay_equals_eager():
         res[graphs] = out
     for a, b in zip(res[False], res[True]):
         for k in a:
-            # w_estimate is a cancelling difference of two O(0.1) means: absolute bound for it
-            assert rel(a[k], b[k]) < 1e-5 or abs(a[k] - b[k]) < 1e-6, (k, a[k], b[k])
+            # w_estimate is a cancelling difference of two O(0.1) means: absolute bound for it.  tools/graph_flake.py (20
+            # repetitions on MI355X): every scalar but w_estimate agrees to <= 4e-7, the trajectories of two runs separate by
+            # the order of the fp32 atomics alone, eager vs eager as much as eager vs replay
+            assert rel(a[k], b[k]) < 5e-5 or abs(a[k] - b[k]) < 5e-6, (k, a[k], b[k])
