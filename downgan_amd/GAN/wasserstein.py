@@ -96,8 +96,8 @@ class WassersteinGAN:
         e = self._engine
         assert e is not None and e.B == B, "call a train iteration first (buffers are shape-bound)"
         o = e.ops
-        xr = o.zeros(*e.xhat.shape); o.nchw_to_nhwc(real.to(o.device, torch.float32).contiguous(), xr)
-        xk = o.zeros(*e.xhat.shape); o.nchw_to_nhwc(fake.to(o.device, torch.float32).contiguous(), xk)
+        xr = o.zeros(*e.fine_shape); o.nchw_to_nhwc(real.to(o.device, torch.float32).contiguous(), xr)
+        xk = o.zeros(*e.fine_shape); o.nchw_to_nhwc(fake.to(o.device, torch.float32).contiguous(), xk)
         o.gp_interp(xr, xk, self._alpha(e, alpha), e.xhat)
         e.C.forward(e.xhat)
         e.C.backward(e.xhat, 1.0, wgrad=False, dx=e.gbuf)

@@ -80,6 +80,8 @@ _PROTOS = {
     "dg_mask_mul": [_i, _vp, _i64, _vp, _i64, _i64, _i, _f, _vp],
     "dg_axpby": [_i, _vp, _i64, _vp, _i64, _f, _vp, _i64, _f, _i64, _i, _vp],
     "dg_gp_interp": [_i, _vp, _vp, _vp, _vp, _i, _i64, _vp],
+    "dg_gp_interp_c2": [_i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i64, _vp],
+    "dg_scale_rows_c2": [_i, _vp, _i64, _vp, _vp, _i, _i64, _vp],
     "dg_sumsq_rows": [_i, _vp, _i, _i64, _vp, _vp],
     "dg_gp_finish": [_vp, _i, _i, _f, _f, _vp, _vp, _vp],
     "dg_scale_rows": [_i, _vp, _vp, _vp, _i, _i64, _vp],

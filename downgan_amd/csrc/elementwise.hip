@@ -1,6 +1,7 @@
 // HBM-bound elementwise / reduction kernels of the train step: 16 B per lane, grid-stride, fp32 math.
 #include <cstdlib>
 #include "dg_internal.h"
+#include <type_traits>
 
 #include <math.h>
 
@@ -96,6 +97,84 @@ extern "C" int dg_gp_interp(int dtype, const void* real, const void* fake, const
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DG_F32) { dim3 g(ew_blocks(per_img / 4) , B); hipLaunchKernelGGL(interp_kernel<float>, g, dim3(256), 0, st, (const float*)real, (const float*)fake, alpha, (float*)xhat, per_img / 4); }
   else if (dtype == DG_BF16) { dim3 g(ew_blocks(per_img / 8), B); hipLaunchKernelGGL(interp_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)real, (const bf16_t*)fake, alpha, (bf16_t*)xhat, per_img / 8); }
+  else return DG_ERR_BAD_DTYPE;
+  return dg_check_launch();
+}
+
+// The 2-channel fields of the fine grid (wasserstein.py:94: real, fake, interpolate) are stored 16 channels wide like every
+// activation; the critic's first layer reads the two real channels only, and its gathers are what bounds it (csrc/gather_gemm.hip,
+// gg_im2col_direct_kernel: 0.79 -> 0.62 ms per 8 images from a compact [pixel][2] source).  These two kernels write the COMPACT
+// forms where the bytes are produced anyway: the interpolate (plus compact copies of its two inputs, which it has in registers)
+// and the penalty's scaled gradient.  One thread = 16 bytes of each output (4 bf16 / 2 fp32 pixels).
+template <typename T>
+__global__ void interp_c2_kernel(const T* real, const T* fake, long long ld, const float* alpha, T* xhat_c, T* real_c, T* fake_c,
+                                 long long pix_per_img) {
+  constexpr int PPT = 8 / (int)sizeof(T);            // pixels per thread
+  typedef typename std::conditional<sizeof(T) == 2, unsigned, uint2>::type pair_t;
+  const int b = blockIdx.y;
+  const float al = alpha[b];
+  const long long pbase = (long long)b * pix_per_img;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pix_per_img / PPT; i += (long long)gridDim.x * blockDim.x) {
+    const long long p0 = pbase + i * PPT;
+    pair_t r[PPT], f[PPT], x[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      r[k] = *reinterpret_cast<const pair_t*>(real + (p0 + k) * ld);
+      f[k] = *reinterpret_cast<const pair_t*>(fake + (p0 + k) * ld);
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const T* rp = reinterpret_cast<const T*>(&r[k]);
+      const T* fp = reinterpret_cast<const T*>(&f[k]);
+      T* xp = reinterpret_cast<T*>(&x[k]);
+      st_elem(xp, al * ld_elem(rp) + (1.f - al) * ld_elem(fp));              // wasserstein.py:94
+      st_elem(xp + 1, al * ld_elem(rp + 1) + (1.f - al) * ld_elem(fp + 1));
+    }
+    *reinterpret_cast<uint4*>(xhat_c + p0 * 2) = *reinterpret_cast<const uint4*>(x);
+    if (real_c) *reinterpret_cast<uint4*>(real_c + p0 * 2) = *reinterpret_cast<const uint4*>(r);
+    if (fake_c) *reinterpret_cast<uint4*>(fake_c + p0 * 2) = *reinterpret_cast<const uint4*>(f);
+  }
+}
+extern "C" int dg_gp_interp_c2(int dtype, const void* real, const void* fake, int64_t ld, const float* alpha, void* xhat_c,
+                               void* real_c, void* fake_c, int B, int64_t pix_per_img, void* stream) {
+  if (!real || !fake || !alpha || !xhat_c) return DG_ERR_BAD_ARG;
+  if (B <= 0 || pix_per_img <= 0 || pix_per_img % 4 || ld < 2 || ld % 2) return DG_ERR_BAD_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DG_F32) { dim3 g(ew_blocks(pix_per_img / 2), B); hipLaunchKernelGGL(interp_c2_kernel<float>, g, dim3(256), 0, st, (const float*)real, (const float*)fake, (long long)ld, alpha, (float*)xhat_c, (float*)real_c, (float*)fake_c, (long long)pix_per_img); }
+  else if (dtype == DG_BF16) { dim3 g(ew_blocks(pix_per_img / 4), B); hipLaunchKernelGGL(interp_c2_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)real, (const bf16_t*)fake, (long long)ld, alpha, (bf16_t*)xhat_c, (bf16_t*)real_c, (bf16_t*)fake_c, (long long)pix_per_img); }
+  else return DG_ERR_BAD_DTYPE;
+  return dg_check_launch();
+}
+
+template <typename T>
+__global__ void scale_rows_c2_kernel(const T* g, long long ld, const float* coef, T* out_c, long long pix_per_img) {
+  constexpr int PPT = 8 / (int)sizeof(T);
+  typedef typename std::conditional<sizeof(T) == 2, unsigned, uint2>::type pair_t;
+  const int b = blockIdx.y;
+  const float cf = coef[b];
+  const long long pbase = (long long)b * pix_per_img;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pix_per_img / PPT; i += (long long)gridDim.x * blockDim.x) {
+    const long long p0 = pbase + i * PPT;
+    pair_t v[PPT], x[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) v[k] = *reinterpret_cast<const pair_t*>(g + (p0 + k) * ld);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const T* vp = reinterpret_cast<const T*>(&v[k]);
+      T* xp = reinterpret_cast<T*>(&x[k]);
+      st_elem(xp, ld_elem(vp) * cf);
+      st_elem(xp + 1, ld_elem(vp + 1) * cf);
+    }
+    *reinterpret_cast<uint4*>(out_c + p0 * 2) = *reinterpret_cast<const uint4*>(x);
+  }
+}
+extern "C" int dg_scale_rows_c2(int dtype, const void* g, int64_t ld, const float* coef, void* out_c, int B, int64_t pix_per_img,
+                                void* stream) {
+  if (!g || !coef || !out_c) return DG_ERR_BAD_ARG;
+  if (B <= 0 || pix_per_img <= 0 || pix_per_img % 4 || ld < 2 || ld % 2) return DG_ERR_BAD_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DG_F32) { dim3 gr(ew_blocks(pix_per_img / 2), B); hipLaunchKernelGGL(scale_rows_c2_kernel<float>, gr, dim3(256), 0, st, (const float*)g, (long long)ld, coef, (float*)out_c, (long long)pix_per_img); }
+  else if (dtype == DG_BF16) { dim3 gr(ew_blocks(pix_per_img / 4), B); hipLaunchKernelGGL(scale_rows_c2_kernel<bf16_t>, gr, dim3(256), 0, st, (const bf16_t*)g, (long long)ld, coef, (bf16_t*)out_c, (long long)pix_per_img); }
   else return DG_ERR_BAD_DTYPE;
   return dg_check_launch();
 }

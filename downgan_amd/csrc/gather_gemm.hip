@@ -147,7 +147,7 @@ __device__ __forceinline__ unsigned epi64_bits(const GGArgs& a, const EpiRes& R,
 template <typename T, bool LEAN, int F = -1>
 __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, const f32x4_t& f0, const f32x4_t& f1, const f32x4_t& f2,
                                             const f32x4_t& f3, const float (&bias)[16], unsigned offy, unsigned off1, unsigned off2,
-                                            unsigned offm, unsigned boff, unsigned mb, bool mask_on) {
+                                            unsigned offm, unsigned boff, unsigned mb, bool mask_on, unsigned* ob_ret = nullptr) {
   typedef EpiV<T> IO;
   constexpr int NU = IO::NU, CPU = IO::CPU;
   u32x4_t v1[NU], v2[NU], vm[NU], va[NU];
@@ -173,8 +173,13 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
     if (f_ac) va[u] = __builtin_amdgcn_raw_buffer_load_b128(R.rY, offy, u * 16, 0);
   }
   float v[16];
+  if (F >= 0 && (F & 512)) {          // the caller's MFMAs already added the bias (gg_im2col_direct_kernel)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { v[e] = f0[e] + bias[e]; v[4 + e] = f1[e] + bias[4 + e]; v[8 + e] = f2[e] + bias[8 + e]; v[12 + e] = f3[e] + bias[12 + e]; }
+    for (int e = 0; e < 4; ++e) { v[e] = f0[e]; v[4 + e] = f1[e]; v[8 + e] = f2[e]; v[12 + e] = f3[e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = f0[e] + bias[e]; v[4 + e] = f1[e] + bias[4 + e]; v[8 + e] = f2[e] + bias[8 + e]; v[12 + e] = f3[e] + bias[12 + e]; }
+  }
   // (pure-ALU parts may sit behind uniform branches: only the memory operations have to be unconditional)
   if (f_act) {
     if (a.act_slope >= 0.f && a.act_slope <= 1.f) {          // max(v, v * slope) == leaky(v) for slopes in [0, 1]: 2 operations, not 3
@@ -225,7 +230,8 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
     pk[u] = IO::pack(vu);
     __builtin_amdgcn_raw_buffer_store_b128(pk[u], R.rY, offy, u * 16, 0);
   }
-  if (F >= 0) { if (f_ob) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, boff, 0, 0); }
+  if (F >= 0 && (F & 1024)) *ob_ret = ob;      // the caller stores the word itself (gg_im2col_direct_kernel: two words per store)
+  else if (F >= 0) { if (f_ob) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, boff, 0, 0); }
   else if (LEAN || a.out_bits) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, (LEAN && !a.out_bits) ? DG_OOB_OFF : boff, 0, 0);
   if constexpr (sizeof(T) == 2) {
     // MXFP8 copy of what was just stored (the bf16-ROUNDED values, so it equals dg_quant_mxfp8 of the stored tensor): the lane
@@ -1958,6 +1964,140 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 2) void gg_im2col_kernel(const GGAr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same layer without LDS and without barriers (bf16, image width a multiple of 16, 128-channel tiles, bias / activation /
+// bit-mask / MXFP8-copy epilogues).  gg_im2col_kernel moves every tile through gather -> LDS -> barrier -> MFMA -> stores ->
+// barrier with 12 waves per CU; its 2.7-3.4 TB/s of stores is per-tile latency, not bandwidth.  Here a WAVE owns a group of 16
+// consecutive pixels of one image row and all 128 channels: the MFMA's B fragment of pixel n is K elements 8g..8g+7 = taps
+// 4g..4g+3 x 2 channels, i.e. four dwords of x (lane groups 0-1: taps 0-7, group 2: tap 8, group 3: nothing), the eight A fragments (18 x 128 weights) live in registers for the whole kernel, and the BIAS rides in the two
+// spare K slots 18/19 of lane group 2 (weight = bias split into a bf16 high and low part, pixel value = 1.0 twice: exact to 2^-17
+// of the bias), so the epilogue is activation + rounding + stores.  Nothing is shared between waves: 16 waves per CU, each with
+// the next group's pixels in flight behind the current group's eight 16-byte stores per lane.  Waves sweep the pixel
+// groups interleaved (group = iteration * waves + wave), so the chip writes one moving window of the output.
+template <int F>
+__global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a, int ngroups, bool tiled) {
+  typedef bf16_t T;
+  constexpr int ES = 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int c0 = blockIdx.y * 128;
+  const T* Wt = reinterpret_cast<const T*>(a.w);
+  uint4 fa[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = c0 + (j >> 2) * 64 + perm64((j & 3) * 16 + l15);      // channel of A row l15 of fragment j (Nout % 128 == 0)
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (g < 2) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) w[tt] = *reinterpret_cast<const unsigned*>(Wt + ((long long)n * 9 + 4 * g + tt) * a.Cred);
+    } else if (g == 2) {
+      w[0] = *reinterpret_cast<const unsigned*>(Wt + ((long long)n * 9 + 8) * a.Cred);
+      const float b = a.bias ? a.bias[n] : 0.f;
+      const bf16_t hi = f32_to_bf16(b), lo = f32_to_bf16(b - bf16_to_f32(hi));
+      w[1] = (unsigned)hi | ((unsigned)lo << 16);
+    }
+    fa[j] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // The 16 pixels of a group read 3 rows x 18 columns of x = 54 dwords (2 channels each): ONE load per lane brings them in
+  // (lane i < 54: row i / 18 - 1, column i % 18 - 1 relative to the group's first pixel; out-of-image -> 0) and four
+  // ds_bpermute_b32 hand every lane its taps (lane constants; K slots past the 9 taps point at lane 63, which always holds 0).
+  // Four gathers per lane straight from x touched ~48 cache lines per group in the 16-channel-padded layout (15 now).
+  const int ld_r = lane / 18 - 1, ld_c = lane % 18 - 1;
+  int perm_src[4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int tp = 4 * g + tt;
+    perm_src[tt] = tp < 9 ? ((tp / 3) * 18 + l15 + tp % 3) * 4 : 63 * 4;
+  }
+  const unsigned ones = g == 2 ? 0x3f803f80u : 0u;                 // K slots 18 / 19 of the pixel operand: bf16 1.0 twice
+  const int ldb = (a.Nout >> 6) * 4;
+  unsigned offy[2], boff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    offy[h] = (unsigned)((l15 * (int)a.ldy + c0 + 64 * h + 16 * g) * ES);
+    boff[h] = (unsigned)((l15 * ldb + ((c0 + 64 * h) >> 6) * 4 + g) * 2);
+  }
+  // out_bits: a pixel's record is 8 words (128 channels); lane group g gets words g (first half) and 4 + g (second half) out of
+  // the two epilogue calls.  Stored as ONE dword per lane -- group g writes words 2g, 2g+1, fetched from groups 2(g&1), 2(g&1)+1
+  // by two ds_bpermute -- so a group's 256 bytes of mask words leave as one contiguous wave store instead of two scattered 2-byte
+  // ones (the two 2-byte stores cost 8-14 % of the launch).
+  const int ob_src = (l15 + 32 * (g & 1)) * 4, ob_sh = 16 * (g >> 1);
+  const unsigned ob_off = (unsigned)((l15 * ldb + (c0 >> 6) * 4 + 2 * g) * 2);
+  const float zero16[16] = {};
+  auto gather = [&](int grp) -> unsigned {
+    const bool live = grp >= 0;
+    const unsigned m0 = live ? (unsigned)grp * 16u : 0u;
+    const unsigned tq = m0 / (unsigned)a.Wg;
+    const int sx = (int)(m0 - tq * (unsigned)a.Wg) + ld_c, sy = (int)(tq % (unsigned)a.Hg) + ld_r;
+    long long pbase = (long long)m0 - a.Ws - 1;
+    if (pbase < 0) pbase = 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) + pbase * a.ldx * ES), 0,
+                                                                      (int)DG_OOB_OFF, 0x00020000);
+    const int mrel = (int)((long long)m0 - pbase) + ld_r * a.Ws + ld_c;
+    const bool ok = (int)live & (int)(lane < 54) & (int)((unsigned)sy < (unsigned)a.Hs) & (int)((unsigned)sx < (unsigned)a.Ws);
+    return __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (unsigned)(mrel * (int)a.ldx * ES) : DG_OOB_OFF, 0, 0);
+  };
+  // group order.  tiled (image height a multiple of 16): a workgroup walks 16x16-pixel tiles, wave w rows 4w..4w+3 of each (the
+  // write pattern of the tiled conv kernels: 3.6 against 3.3 TB/s for the linear order, whose 4096 waves write one 16-MB window);
+  // otherwise wave k of the grid takes groups k, k + waves, ...
+  const int nwaves = (int)gridDim.x * 4;
+  const int tiles_x = a.Wg / 16, tiles_y = a.Hg / 16, ntiles = tiled ? tiles_x * tiles_y * (a.M / (a.Hg * a.Wg)) : 0;
+  auto grp_of = [&](int it) -> int {                 // < 0: past this wave's last group
+    if (!tiled) { const int gq = (int)blockIdx.x * 4 + wave + it * nwaves; return gq < ngroups ? gq : -1; }
+    unsigned tile = blockIdx.x + (unsigned)(it >> 2) * gridDim.x;
+    if (tile >= (unsigned)ntiles) return -1;
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int ty = tile % tiles_y, img = tile / tiles_y;
+    return ((img * a.Hg + ty * 16 + 4 * wave + (it & 3)) * a.Wg + tx * 16) >> 4;
+  };
+  // a group's pixels are fetched two groups ahead (memory operations retire in order: a load comes back only after the stores
+  // issued before it have been acknowledged)
+  unsigned x0 = gather(grp_of(0)), x1 = gather(grp_of(1));
+  for (int it = 0;; ++it) {
+    const int grp = grp_of(it);
+    if (grp < 0) break;
+    const uint4 fb = make_uint4((unsigned)__builtin_amdgcn_ds_bpermute(perm_src[0], (int)x0),
+                                (unsigned)__builtin_amdgcn_ds_bpermute(perm_src[1], (int)x0) | ones,
+                                (unsigned)__builtin_amdgcn_ds_bpermute(perm_src[2], (int)x0),
+                                (unsigned)__builtin_amdgcn_ds_bpermute(perm_src[3], (int)x0));
+    const long long m0 = (long long)grp * 16;
+    auto rsrc = [&](const void* p, long long ld, int es) {
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + m0 * ld * es), 0, (int)DG_OOB_OFF, 0x00020000);
+    };
+    EpiRes R;
+    R.rY = rsrc(a.y, a.ldy, ES);
+    R.r1 = R.r2 = R.rm = R.rY;
+    R.rbi = (F & 2) ? rsrc(a.mask_bits, ldb, 2) : R.rY; R.rbo = (F & 4) ? rsrc(a.out_bits, ldb, 2) : R.rY;
+    R.rq = (F & 256) ? rsrc(a.out_q, a.ldy, 1) : R.rY; R.rqs = (F & 256) ? rsrc(a.out_qs, a.ldqs, 1) : R.rY;
+    R.ldy = (int)a.ldy; R.ld1 = R.ld2 = R.ldm = 0;
+    unsigned mb[2] = {0u, 0u};
+    if (F & 2) {                                                   // both mask words before the first store
+      mb[0] = __builtin_amdgcn_raw_buffer_load_b16(R.rbi, boff[0], 0, 0);
+      mb[1] = __builtin_amdgcn_raw_buffer_load_b16(R.rbi, boff[1], 0, 0);
+    }
+    const unsigned x2 = gather(grp_of(it + 2));
+    unsigned ob[2] = {0u, 0u};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4_t acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        Mma<T>::run(fa[4 * h + j], fb, acc[j]);
+      }
+      epi64_pixel<T, true, F | 512 | ((F & 4) ? 1024 : 0)>(a, R, acc[0], acc[1], acc[2], acc[3], zero16, offy[h], 0u, 0u, 0u, boff[h], mb[h],
+                                                            false, &ob[h]);
+    }
+    if (F & 4) {
+      const int both = (int)(ob[0] | (ob[1] << 16));
+      const unsigned lo = ((unsigned)__builtin_amdgcn_ds_bpermute(ob_src, both) >> ob_sh) & 0xffffu;
+      const unsigned hi = ((unsigned)__builtin_amdgcn_ds_bpermute(ob_src + 64, both) >> ob_sh) & 0xffffu;
+      __builtin_amdgcn_raw_buffer_store_b32(lo | (hi << 16), R.rbo, ob_off, 0, 0);
+    }
+    x0 = x1; x1 = x2;
+  }
+}
+
 template <typename T>
 static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
   const int tiles = (a.M + 127) / 128;
@@ -1967,6 +2107,28 @@ static int gg_launch_im2col(GGArgs& a, hipStream_t st) {
   // big launches: ONE round of the resident workgroups, every workgroup the same number of tiles (16 tiles per workgroup
   // left 16384 workgroups on 768 slots: 21.3 rounds, the last a third full; +2 % at 1024^2)
   const bool lean = !a.r1 && !a.r2 && !a.mask && !a.accumulate;
+  if constexpr (sizeof(T) == 2) {
+    static const bool no_direct = getenv("DG_GG_NOIM2COLDIRECT") != nullptr;
+    const int F = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.out_q ? 256 : 0);
+    if (!no_direct && lean && a.Wg % 16 == 0 && a.Nout % 128 == 0 && a.Hs == a.Hg && a.Ws == a.Wg &&
+        (long long)a.M * a.ldy * 2 < (1ll << 46) && (F == 0 || F == 1 || F == 2 || F == 5 || F == 258 || F == 261)) {
+      const int ngroups = a.M / 16;
+      int nb = a.Hg % 16 == 0 ? ngroups / 16 : (ngroups + 3) / 4;   // tiles of 16 groups / workgroups of 4 groups
+      if (nb > 1024) nb = 1024;                                    // 4 workgroups per CU resident, one round
+      dim3 grid(nb, a.Nout / 128);
+      g_last_kinds |= 16;
+      const bool tiled = a.Hg % 16 == 0;
+      switch (F) {
+        case 0: hipLaunchKernelGGL((gg_im2col_direct_kernel<0>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 1: hipLaunchKernelGGL((gg_im2col_direct_kernel<1>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 2: hipLaunchKernelGGL((gg_im2col_direct_kernel<2>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 5: hipLaunchKernelGGL((gg_im2col_direct_kernel<5>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 258: hipLaunchKernelGGL((gg_im2col_direct_kernel<258>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        default: hipLaunchKernelGGL((gg_im2col_direct_kernel<261>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+      }
+      return dg_check_launch();
+    }
+  }
   static std::atomic<int> occ_cache[2] = {{0}, {0}};
   int occ = occ_cache[lean].load(std::memory_order_relaxed);
   if (!occ) {

@@ -855,7 +855,11 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
   if (g->Cin % 8 || g->Cout % 16 || g->Cin <= 0 || g->Cout <= 0) return DG_ERR_BAD_SHAPE;
   if (g->pixel_shuffle && (g->stride != 1 || (g->Cout / 4) % 16)) return DG_ERR_BAD_SHAPE;
   const int epc = g->dtype == DG_F32 ? 4 : 8;
-  if (g->ldx % epc || g->ldy % epc) return DG_ERR_BAD_SHAPE;
+  // the im2col kernel (<= 2 real input channels) gathers single (channel 0, channel 1) pairs, so its x may be the COMPACT
+  // tensor [N, H, W, 2] (ldx = 2); every other kernel reads whole 16-byte channel chunks
+  const bool im2col_shape = g->cin_real > 0 && g->cin_real <= 2 && g->stride == 1 && !g->pixel_shuffle && (g->W / g->stride) % 32 == 0 &&
+                            getenv("DG_WG_NOIM2COL") == nullptr;
+  if ((im2col_shape ? (g->ldx % 2 || g->ldx < 2) : (g->ldx % epc != 0)) || g->ldy % epc) return DG_ERR_BAD_SHAPE;
   WGArgs a{};
   a.x = x; a.u = dy; a.dw = dw; a.ldx = g->ldx; a.ldu = g->ldy;
   a.H = g->H; a.W = g->W; a.stride = g->stride; a.Ho = g->H / g->stride; a.Wo = g->W / g->stride;

@@ -682,9 +682,21 @@ class TrainEngine:
         self.C = NativeCritic(ops, filters, fine, n_predictands, batch)
         assert self.C.c_pad[0] == self.G.np_p
         o = ops
-        self.xhat = o.zeros(batch, fine, fine, self.G.np_p)
-        self.gbuf = o.zeros(batch, fine, fine, self.G.np_p)
-        self.vbuf = o.zeros(batch, fine, fine, self.G.np_p)
+        # Fields of the fine grid are stored np_p (16) channels wide like every activation.  With <= 2 predictands the critic's
+        # first layer reads two real channels and its kernels are gather-bound on that layout (csrc/gather_gemm.hip:
+        # gg_im2col_direct_kernel), so everything it reads also exists in COMPACT form [B, fine, fine, 2], written where the bytes
+        # are produced anyway: the interpolate x-hat and the penalty's scaled gradient are compact only, and the interpolate pass
+        # also leaves compact copies of its two inputs (the real and the generated batch) for their own critic passes.
+        self.fine_shape = (batch, fine, fine, self.G.np_p)
+        # (the weight-gradient kernel that takes the compact form needs rows of a multiple of 32 pixels)
+        self.compact2 = bool(self.C.convs[0].cin_real) and fine % 32 == 0 and not any(
+            os.environ.get(k) is not None for k in ("DG_NO_COMPACT2", "DG_WG_NOIM2COL", "DG_GG_NOIM2COL"))
+        cshape = (batch, fine, fine, 2) if self.compact2 else self.fine_shape
+        self.xhat = o.zeros(*cshape)
+        self.gbuf = o.zeros(*self.fine_shape)
+        self.vbuf = o.zeros(*cshape)
+        self.real_c = o.zeros(*cshape) if self.compact2 else None
+        self.fake_c = o.zeros(*cshape) if self.compact2 else None
         self.dfake = None
         self.ss = o.zeros(batch, dtype=torch.float32)
         self.coef = o.zeros(batch, dtype=torch.float32)
@@ -729,19 +741,25 @@ class TrainEngine:
         o, hp, C, B = self.ops, self.hp, self.C, self.B
         bg = B * self.world
         real_first = self.G.P._pending is not None
+        xr = fine
         if not real_first:
             fake = self.G.forward(coarse, save=save_g)            # :35
+            if self.compact2:                                     # :94, hoisted: it also writes the compact real / fake batches
+                o.gp_interp(fine, fake, alpha, self.xhat, self.real_c, self.fake_c)
+                xr = self.real_c
         s0, s1, s2 = (0, 1, 2) if C.fc1_fused else (None, None, None)
         C.P.zero_grad(skip="classifier.0.weight" if C.fc1_fused else None)    # :43 (fc1_flush WRITES that gradient)
-        out = C.forward(fine, s0)                                 # :37
+        out = C.forward(xr, s0)                                   # :37
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
-        C.backward(fine, -1.0 / bg, fc1_slot=s0)                  # d(-mean c_real)
+        C.backward(xr, -1.0 / bg, fc1_slot=s0)                    # d(-mean c_real)
         if real_first:
             fake = self.G.forward(coarse, save=save_g)            # :35 (first use of G's parameters completes their update)
-        out = C.forward(fake, s1)                                 # :38
+        if real_first or not self.compact2:
+            o.gp_interp(fine, fake, alpha, self.xhat, None, self.fake_c)      # :94
+        xk = self.fake_c if self.compact2 else fake
+        out = C.forward(xk, s1)                                   # :38
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
-        C.backward(fake, 1.0 / bg, fc1_slot=s1)                   # d(+mean c_fake)
-        o.gp_interp(fine, fake, alpha, self.xhat)                 # :94
+        C.backward(xk, 1.0 / bg, fc1_slot=s1)                     # d(+mean c_fake)
         C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, fc1_slot=s2)   # :40,:87-117
         if C.fc1_fused:
             C.fc1_flush()
@@ -758,7 +776,7 @@ class TrainEngine:
             self.dfake = o.zeros(*self.G.fake.shape)
         G.P.zero_grad()                                           # :65
         fake = G.fake if reuse_fake else G.forward(coarse, save=True)   # :67
-        out = C.forward(fake)                                     # :68
+        out = C.forward(self.fake_c if reuse_fake and self.compact2 else fake)    # :68 (the critic iteration's compact copy)
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("g_c_fake_mean"))
         C.backward(fake, -hp.gamma / bg, wgrad=False, dx=self.gbuf)            # d(-gamma*mean c_fake)/d fake
         self._sc("l1_sum").zero_()
@@ -875,7 +893,7 @@ class TrainEngineFS(TrainEngine):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         o = self.ops
-        shape = self.xhat.shape
+        shape = self.fine_shape
         self.real_high, self.fake_high = o.zeros(*shape), o.zeros(*shape)
         self.real_low = self.fake_low = self.tbuf = None
 
@@ -886,15 +904,16 @@ class TrainEngineFS(TrainEngine):
         fake = self.G.forward(coarse, save=save_g)                # :36
         o.lowpass5(fake, high=self.fake_high)                     # :37,40
         o.lowpass5(fine, high=self.real_high)                     # :38,41
+        o.gp_interp(self.real_high, self.fake_high, alpha, self.xhat, self.real_c, self.fake_c)   # :46 -> _gp(real_high, fake_high)
+        xr, xk = (self.real_c, self.fake_c) if self.compact2 else (self.real_high, self.fake_high)
         s0, s1, s2 = (0, 1, 2) if C.fc1_fused else (None, None, None)
         C.P.zero_grad(skip="classifier.0.weight" if C.fc1_fused else None)    # :49 (fc1_flush WRITES that gradient)
-        out = C.forward(self.real_high, s0)                       # :43
+        out = C.forward(xr, s0)                                   # :43
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
-        C.backward(self.real_high, -1.0 / bg, fc1_slot=s0)
-        out = C.forward(self.fake_high, s1)                       # :44
+        C.backward(xr, -1.0 / bg, fc1_slot=s0)
+        out = C.forward(xk, s1)                                   # :44
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
-        C.backward(self.fake_high, 1.0 / bg, fc1_slot=s1)
-        o.gp_interp(self.real_high, self.fake_high, alpha, self.xhat)          # :46 -> _gp(real_high, fake_high)
+        C.backward(xk, 1.0 / bg, fc1_slot=s1)
         C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, fc1_slot=s2)
         if C.fc1_fused:
             C.fc1_flush()
@@ -909,7 +928,7 @@ class TrainEngineFS(TrainEngine):
         if self.dfake is None:
             self.dfake = o.zeros(*self.G.fake.shape)
         if self.tbuf is None:
-            self.real_low, self.fake_low, self.tbuf = (o.zeros(*self.xhat.shape) for _ in range(3))
+            self.real_low, self.fake_low, self.tbuf = (o.zeros(*self.fine_shape) for _ in range(3))
         G.P.zero_grad()                                           # :70
         fake = G.fake if reuse_fake else G.forward(coarse, save=True)   # :72
         o.lowpass5(fake, low=self.fake_low, high=self.fake_high)  # :73,76

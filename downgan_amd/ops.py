@@ -283,7 +283,8 @@ class HipOps:
         self._act(x); self._act(dy)
         assert dw.dtype == torch.float32 and dw.numel() == cv.Cout * 9 * cv.Cin and dw.is_contiguous()
         assert db is None or (db.dtype == torch.float32 and db.numel() >= cv.Cout and not cv.pixel_shuffle)
-        assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin), (x.shape, cv)
+        # layers with <= 2 real input channels (im2col kernel) also take the COMPACT form [N, H, W, 2] of their input
+        assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin) or (cv.cin_real and tuple(x.shape) == (cv.N, cv.H, cv.W, 2) and cv.stride == 1), (x.shape, cv)
         assert tuple(dy.shape) == self.out_shape(cv), (dy.shape, cv)
         g = self._geom(cv, pix_layout(x)[0], pix_layout(dy)[0])
         check(self._timed("conv_wgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad(
@@ -396,10 +397,23 @@ class HipOps:
         check(self.lib.dg_axpby(self.dg, _ptr(out), ldo, _ptr(x), pix_layout(x)[0], float(a), _ptr(y),
                                 pix_layout(y)[0] if y is not None else 0, float(b), rows, x.shape[-1], self._stream()), "dg_axpby")
 
-    def gp_interp(self, real, fake, alpha, xhat):
+    def gp_interp(self, real, fake, alpha, xhat, real_c=None, fake_c=None):
+        """xhat = alpha * real + (1 - alpha) * fake per sample.  With a COMPACT ``xhat`` [B, H, W, 2] (fields stored wider with
+        two real channels) the compact forms of the inputs can be written in the same pass (``real_c`` / ``fake_c``)."""
+        assert alpha.dtype == torch.float32 and alpha.numel() == real.shape[0] and real.shape == fake.shape
         for t in (real, fake, xhat):
-            self._act(t); assert t.is_contiguous() and t.shape == real.shape
-        assert alpha.dtype == torch.float32 and alpha.numel() == real.shape[0]
+            self._act(t); assert t.is_contiguous()
+        if xhat.shape[-1] == 2 and real.shape[-1] > 2:
+            assert tuple(xhat.shape[:-1]) == tuple(real.shape[:-1])
+            for t in (real_c, fake_c):
+                assert t is None or (t.shape == xhat.shape and t.is_contiguous() and t.dtype == xhat.dtype)
+            n_out = 1 + (real_c is not None) + (fake_c is not None)
+            check(self._timed("ew_gp_interp", 0.0, lambda: self.lib.dg_gp_interp_c2(
+                self.dg, _ptr(real), _ptr(fake), real.shape[-1], _ptr(alpha), _ptr(xhat), _ptr(real_c), _ptr(fake_c), real.shape[0],
+                real[0].numel() // real.shape[-1], self._stream()),
+                (2.0 * real.numel() + n_out * xhat.numel()) * real.element_size(), "C"), "dg_gp_interp_c2")
+            return
+        assert xhat.shape == real.shape and real_c is None and fake_c is None
         check(self._timed("ew_gp_interp", 0.0, lambda: self.lib.dg_gp_interp(
             self.dg, _ptr(real), _ptr(fake), _ptr(alpha), _ptr(xhat), real.shape[0], real[0].numel(), self._stream()),
             3.0 * real.numel() * real.element_size(), "C"), "dg_gp_interp")
@@ -413,7 +427,15 @@ class HipOps:
         check(self.lib.dg_gp_finish(_ptr(ss), B, B_global, float(gp_lambda), float(weight), _ptr(coef), _ptr(scalar_out), self._stream()), "dg_gp_finish")
 
     def scale_rows(self, g, coef, out):
+        """out[b] = coef[b] * g[b]; a COMPACT ``out`` [B, H, W, 2] takes the two real channels of a wider ``g``."""
         self._act(g); self._act(out); assert g.is_contiguous() and out.is_contiguous()
+        if out.shape[-1] == 2 and g.shape[-1] > 2:
+            assert tuple(out.shape[:-1]) == tuple(g.shape[:-1])
+            check(self._timed("ew_scale_rows", 0.0, lambda: self.lib.dg_scale_rows_c2(
+                self.dg, _ptr(g), g.shape[-1], _ptr(coef), _ptr(out), g.shape[0], g[0].numel() // g.shape[-1], self._stream()),
+                (g.numel() + out.numel()) * g.element_size(), "C"), "dg_scale_rows_c2")
+            return
+        assert out.shape == g.shape
         check(self._timed("ew_scale_rows", 0.0, lambda: self.lib.dg_scale_rows(
             self.dg, _ptr(g), _ptr(coef), _ptr(out), g.shape[0], g[0].numel(), self._stream()), 2.0 * g.numel() * g.element_size(), "C"), "dg_scale_rows")
 

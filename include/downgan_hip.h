@@ -199,6 +199,15 @@ int dg_axpby(int dtype, void* out, int64_t ldo, const void* x, int64_t ldx, floa
 /* xhat[b] = alpha[b]*real[b] + (1-alpha[b])*fake[b]   (wasserstein.py:94). per_img = elements/image */
 int dg_gp_interp(int dtype, const void* real, const void* fake, const float* alpha, void* xhat,
                  int B, int64_t per_img, void* stream);
+/* The same interpolate for fields stored `ld` channels wide of which the first TWO are real: writes the COMPACT [pixel][2]
+ * forms the critic's first layer reads fastest (dg_conv3x3_fwd / _wgrad with cin_real <= 2 take either layout) -- xhat_c, and
+ * (optional, may be NULL) compact copies real_c / fake_c of the two inputs.  pix_per_img % 4 == 0. */
+int dg_gp_interp_c2(int dtype, const void* real, const void* fake, int64_t ld, const float* alpha,
+                    void* xhat_c, void* real_c, void* fake_c, int B, int64_t pix_per_img, void* stream);
+/* out_c[b][pixel][0..1] = coef[b] * g[b][pixel][0..1]  (the penalty's v0 = dGP/dg, wasserstein.py:110-117 backward), g stored
+ * `ld` channels wide, out_c compact. */
+int dg_scale_rows_c2(int dtype, const void* g, int64_t ld, const float* coef, void* out_c, int B,
+                     int64_t pix_per_img, void* stream);
 /* ss[b] (fp32, pre-zeroed) += sum of squares of image b   (wasserstein.py:114), wave-shuffle reduce */
 int dg_sumsq_rows(int dtype, const void* g, int B, int64_t per_img, float* ss, void* stream);
 /* From ss[b]: n_b = sqrt(ss+1e-12); scalars[0] = gp_lambda*mean((n_b-1)^2)  (wasserstein.py:117);

@@ -184,7 +184,15 @@ class EmuOps:
         """dequantised fp32 value of an operand: from its producer-written MXFP8 form if given, else quantised here."""
         return self.mx_dequant(*pre).reshape(t.shape) if pre is not None else self.mx_quant(t)[2]
 
+    @staticmethod
+    def _widen(cv, x):
+        """COMPACT [N, H, W, 2] input of a layer with <= 2 real input channels -> the padded form the restatement walks."""
+        if cv.cin_real and x.shape[-1] == 2 and cv.Cin > 2:
+            return torch.nn.functional.pad(x, (0, cv.Cin - 2))
+        return x
+
     def conv_fwd(self, cv: Conv, x, w_fwd, y, xq=None, wq=None, **ep):
+        x = self._widen(cv, x)
         assert tuple(x.shape) == (cv.N, cv.H, cv.W, cv.Cin) and tuple(y.shape) == self.out_shape(cv)
         (d,) = self._plan(cv, 0, pix_layout(x)[0], pix_layout(y)[0])
         if self.f8_eligible(cv, "fwd"):       # fp8 operands, exact products, fp32 accumulation
@@ -201,6 +209,7 @@ class EmuOps:
             self._gather_gemm(d, dy, w_dgrad, dx, **ep)
 
     def conv_wgrad(self, cv: Conv, x, dy, dw, db=None):
+        x = self._widen(cv, x)
         if db is not None:
             self.colsum(dy, db)
         u = dy.float()
@@ -282,9 +291,14 @@ class EmuOps:
             v = v + b * y.float()
         out.copy_(v.to(out.dtype))
 
-    def gp_interp(self, real, fake, alpha, xhat):
+    def gp_interp(self, real, fake, alpha, xhat, real_c=None, fake_c=None):
         a = alpha.view(-1, 1, 1, 1)
-        xhat.copy_((a * real.float() + (1 - a) * fake.float()).to(xhat.dtype))
+        c = xhat.shape[-1]                  # compact outputs take the leading channels
+        xhat.copy_((a * real[..., :c].float() + (1 - a) * fake[..., :c].float()).to(xhat.dtype))
+        if real_c is not None:
+            real_c.copy_(real[..., :c])
+        if fake_c is not None:
+            fake_c.copy_(fake[..., :c])
 
     def sumsq_rows(self, g, ss):
         ss += (g.float() ** 2).reshape(g.shape[0], -1).sum(1)
@@ -296,7 +310,7 @@ class EmuOps:
         scalar_out[0] = gp_lambda * (d * d).sum() / B_global
 
     def scale_rows(self, g, coef, out):
-        out.copy_((g.float() * coef[:g.shape[0]].view(-1, 1, 1, 1)).to(out.dtype))
+        out.copy_((g[..., :out.shape[-1]].float() * coef[:g.shape[0]].view(-1, 1, 1, 1)).to(out.dtype))
 
     def l1(self, a, b, acc, grad=None, grad_scale=0.0, addend=None):
         d = a.float() - b.float()

@@ -330,6 +330,51 @@ def test_conv_wgrad_small_cin_with_bias(dtype, N, H, W, co, cin_real):
     tol = 1e-5 if dtype == "f32" else 1e-4
     assert (dw.cpu() - dw_ref).abs().max().item() <= tol * 8 * float(dw_ref.abs().max())
     assert (db.cpu() - db_ref).abs().max().item() <= tol * 8 * float(db_ref.abs().max())
+    if W % 32 == 0:        # the same gradient from the COMPACT [N, H, W, 2] form of x (what the train engine feeds the first layer)
+        dw2, db2 = torch.zeros(co * 9 * 16).cuda(), torch.zeros(co).cuda()
+        dw1, db1 = torch.zeros(co * 9 * 16).cuda(), torch.zeros(co).cuda()
+        hip.conv_wgrad(cv, x.cuda(), dy.cuda(), dw1, db=db1)
+        hip.conv_wgrad(cv, x[..., :2].contiguous().cuda(), dy.cuda(), dw2, db=db2)
+        scale = float(dw1.abs().max())
+        assert (dw1 - dw2).abs().max().item() <= 1e-5 * scale and (db1 - db2).abs().max().item() <= 1e-5 * float(db1.abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_compact_two_channel_fields(dtype):
+    """dg_gp_interp_c2 / dg_scale_rows_c2: the interpolate, compact copies of its inputs and the penalty's scaled gradient as
+    [B, H, W, 2] from fields stored 16 channels wide; and the first-layer forward from either layout gives identical bits."""
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(31)
+    B, H, W = 3, 32, 64
+    real = torch.zeros(B, H, W, 16, dtype=emu.tdtype); real[..., :2] = rnd((B, H, W, 2), emu.tdtype, g)
+    fake = torch.zeros(B, H, W, 16, dtype=emu.tdtype); fake[..., :2] = rnd((B, H, W, 2), emu.tdtype, g)
+    alpha = torch.rand(B, generator=g)
+    full = torch.zeros_like(real); emu.gp_interp(real, fake, alpha, full)
+    xc, rc, fc = (torch.full((B, H, W, 2), 7.0, dtype=emu.tdtype).cuda() for _ in range(3))
+    hip.gp_interp(real.cuda(), fake.cuda(), alpha.cuda(), xc, rc, fc)
+    assert torch.equal(rc.cpu(), real[..., :2]) and torch.equal(fc.cpu(), fake[..., :2])
+    close(xc, full[..., :2], dtype, "gp_interp_c2")
+    dev_full = torch.zeros_like(real).cuda(); hip.gp_interp(real.cuda(), fake.cuda(), alpha.cuda(), dev_full)
+    assert torch.equal(xc, dev_full[..., :2]), "compact and padded interpolates must round identically"
+    xc2 = torch.zeros(B, H, W, 2, dtype=emu.tdtype).cuda()
+    hip.gp_interp(real.cuda(), fake.cuda(), alpha.cuda(), xc2)          # without the copies
+    assert torch.equal(xc2, xc)
+    coef = torch.randn(B, generator=g)
+    ref = torch.zeros_like(real); emu.scale_rows(real, coef, ref)
+    vc = torch.zeros(B, H, W, 2, dtype=emu.tdtype).cuda()
+    hip.scale_rows(real.cuda(), coef.cuda(), vc)
+    close(vc, ref[..., :2], dtype, "scale_rows_c2")
+    # emulator: same compact semantics (the CPU engine tests run the compact path through it)
+    e_xc, e_rc = torch.zeros(B, H, W, 2, dtype=emu.tdtype), torch.zeros(B, H, W, 2, dtype=emu.tdtype)
+    emu.gp_interp(real, fake, alpha, e_xc, e_rc, None)
+    assert torch.equal(e_xc, full[..., :2]) and torch.equal(e_rc, real[..., :2])
+    cv = Conv(B, H, W, 16, 128, 1, False, cin_real=2)
+    w = torch.zeros(128, 9, 16, dtype=emu.tdtype); w[..., :2] = rnd((128, 9, 2), emu.tdtype, g, 0.3)
+    b = torch.randn(128, generator=g)
+    y1, y2 = hip.zeros(*hip.out_shape(cv)), hip.zeros(*hip.out_shape(cv))
+    hip.conv_fwd(cv, real.cuda(), w.reshape(-1).cuda(), y1, bias=b.cuda(), act=0.2)
+    hip.conv_fwd(cv, rc, w.reshape(-1).cuda(), y2, bias=b.cuda(), act=0.2)
+    assert torch.equal(y1, y2)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
