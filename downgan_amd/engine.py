@@ -439,8 +439,8 @@ class NativeGenerator:
         addconv("conv1", self.cv_conv1, dgrad=False)
         for i in range(num_res_blocks):
             for j in range(3):
-                for k in range(1, 6):
-                    addconv(f"res_blocks.{i}.dense_blocks.{j}.b{k}.0", self.cv_b[k - 1])
+                for k in range(1, 6):       # the dense blocks' data gradients run on the stacked packs below, not per conv
+                    addconv(f"res_blocks.{i}.dense_blocks.{j}.b{k}.0", self.cv_b[k - 1], dgrad=False)
         addconv("conv2", self.cv_conv2)
         for u in range(num_upsample):
             addconv(f"upsampling.{3 * u}", self.cv_up[u])
@@ -468,6 +468,17 @@ class NativeGenerator:
             P.after_refresh.append(lambda: o.repack(P.master("conv3.2.weight").reshape(-1), self._w_c32_bwd, self.np_p, F_, 2))
         self._wq = {}
         self._qlast = None
+        # Dense-block backward (generator.py:14-41).  Conv k of a block reads slab channels [0, kF), so autograd hands the block
+        # five data gradients with 128 reduction channels and k*128 output channels each, the later ones accumulating into the
+        # earlier ones' output: 18 tap-steps per 64-KB read-modify-write epilogue (930-1090 TFLOP/s against the forward's 1250-1290).
+        # The same sums GATHERED by slab slice: the adjoint of slice j is ONE data gradient over the stacked adjoints of convs
+        # j+1..5 -- a "virtual" conv of F input and (5-j)F output channels whose weight rows are the slice-j columns of those
+        # convs -- i.e. exactly the forward's shapes (reduction 128..640 channels, 128 outputs, one plain epilogue per tile).
+        self.cv_v = [Conv(B, S, S, F_, (5 - j) * F_, net="G") for j in range(5)]
+        self._vsize = [(5 - j) * F_ * 9 * F_ for j in range(5)]
+        self._vpack = [o.zeros(sum(self._vsize)) for _ in range(self.ndrb)]
+        self._vtmp = o.zeros(5 * F_ * 9 * F_, dtype=torch.float32)
+        P.after_refresh.append(self._rebuild_vpacks)
         if self.f8:
             P.after_refresh.append(self._requantise_weights)
 
@@ -519,6 +530,23 @@ class NativeGenerator:
 
     def grad_dict(self):
         return self.unpack(self.P.to_host(self.P.g))
+
+    def vpack(self, d, j):
+        """data-gradient pack of dense block d's virtual conv for slab slice j (see __init__)"""
+        off = sum(self._vsize[:j])
+        return self._vpack[d][off:off + self._vsize[j]]
+
+    def _rebuild_vpacks(self):
+        """after every optimizer step / load: rows (k-j-1)F.. of slice j's virtual weight = columns [jF, (j+1)F) of conv k."""
+        o, P, F_ = self.ops, self.P, self.F
+        for d in range(self.ndrb):
+            pre = f"res_blocks.{d // 3}.dense_blocks.{d % 3}.b"
+            ws = [P.view(P.p, f"{pre}{k}.0.weight") for k in range(1, 6)]           # [F, 9, kF] fp32 masters
+            for j in range(5):
+                n = self._vsize[j]
+                tmp = self._vtmp[:n].view((5 - j) * F_, 9, F_)
+                torch.cat([ws[k - 1][:, :, j * F_:(j + 1) * F_] for k in range(j + 1, 6)], 0, out=tmp)
+                o.repack(self._vtmp[:n], self.vpack(d, j), (5 - j) * F_, F_, 1)
 
     # ---- forward -----------------------------------------------------------------------------------
     def _slab(self, d, save):
@@ -584,7 +612,7 @@ class NativeGenerator:
             self._bwd = dict(
                 d_c30=o.zeros(B, hs, hs, F_), d_ups=[o.zeros(B, S << (u + 1), S << (u + 1), F_) for u in range(self.nup)],
                 d_trunk=o.zeros(B, S, S, F_), gy=[o.zeros(B, S, S, F_), o.zeros(B, S, S, F_)], go=o.zeros(B, S, S, F_),
-                d5=o.zeros(B, S, S, F_), gslab=[o.zeros(B, S, S, 5 * F_), o.zeros(B, S, S, 5 * F_)])
+                gx=[o.zeros(B, S, S, F_), o.zeros(B, S, S, F_)], us=[o.zeros(B, S, S, 5 * F_), o.zeros(B, S, S, 5 * F_)])
         bw = self._bwd
         W = lambda n: P.w(n + ".weight")
         WD = lambda n: P.wd(n + ".weight")
@@ -632,24 +660,19 @@ class NativeGenerator:
             o.axpby(go, gy, RES_SCALE)                    # d o_{3i+2}
             for j in (2, 1, 0):
                 d = 3 * i + j
-                slab, gs = self._saved[d], bw["gslab"][d & 1]
+                # adjoint slab: channels [(k-1)F, kF) = u_k, the adjoint of conv k's output (k = 1..5); u_5 = 0.2 * d o
+                slab, us, gx = self._saved[d], bw["us"][d & 1], bw["gx"][d & 1]
                 pre = f"res_blocks.{i}.dense_blocks.{j}.b"
-                o.axpby(bw["d5"], go, RES_SCALE)          # d b5-out = 0.2 * d o
-                o.conv_wgrad(self.cv_b[4], slab, bw["d5"], GW(f"{pre}5.0"), db=GB(f"{pre}5.0"))
-                # Slice k of the gradient slab is complete once conv k+1's data gradient has added its share (conv 5's for
-                # k = 4); that launch multiplies the slice by LeakyReLU'(b_k output) in its own epilogue (mask_c0 / mask_last)
-                # instead of a separate read-modify-write pass over the slice.
-                o.conv_dgrad(self.cv_b[4], bw["d5"], WD(f"{pre}5.0"), gs, mask=slab, mask_slope=G_SLOPE, mask_c0=4 * F_, mask_last=True)
-                o.axpby(gs[..., :F_], gs[..., :F_], 1.0, go, 1.0)        # + identity path of o = 0.2*b5 + x
+                o.axpby(us[..., 4 * F_:], go, RES_SCALE)
+                o.conv_wgrad(self.cv_b[4], slab, us[..., 4 * F_:], GW(f"{pre}5.0"), db=GB(f"{pre}5.0"))
                 for k in range(4, 0, -1):
-                    uk = gs[..., k * F_:(k + 1) * F_]
+                    # u_k = LeakyReLU'(b_k) * sum_{m > k} W_m[:, slice k]^T (*) u_m: one data gradient over u_{k+1..5}
+                    uk = us[..., (k - 1) * F_:k * F_]
+                    o.conv_dgrad(self.cv_v[k], us[..., k * F_:], self.vpack(d, k), uk, mask=slab[..., k * F_:(k + 1) * F_], mask_slope=G_SLOPE)
                     o.conv_wgrad(self.cv_b[k - 1], slab[..., :k * F_], uk, GW(f"{pre}{k}.0"), db=GB(f"{pre}{k}.0"))
-                    if k > 1:
-                        o.conv_dgrad(self.cv_b[k - 1], uk, WD(f"{pre}{k}.0"), gs[..., :k * F_], accumulate=True,
-                                     mask=slab[..., :k * F_], mask_slope=G_SLOPE, mask_c0=(k - 1) * F_, mask_last=True)
-                    else:
-                        o.conv_dgrad(self.cv_b[0], uk, WD(f"{pre}1.0"), gs[..., :F_], accumulate=True)
-                go = gs[..., :F_]                         # d x_drb = d o of the previous dense block
+                # d x_drb = sum_m W_m[:, slice 0]^T (*) u_m + d o (identity path of o = 0.2*b5 + x) = d o of the previous dense block
+                o.conv_dgrad(self.cv_v[0], us, self.vpack(d, 0), gx, r1=go, s1=1.0)
+                go = gx
             gyn = bw["gy"][gyi ^ 1]
             o.axpby(gyn, go, 1.0, gy, 1.0)                # d x_rrdb = d x_drb(3i) + d y (identity path)
             gy, gyi = gyn, gyi ^ 1
