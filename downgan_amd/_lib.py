@@ -66,6 +66,7 @@ _PROTOS = {
     "dg_conv3x3_fwd": [C.POINTER(ConvGeom), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_dgrad": [C.POINTER(ConvGeom), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_wgrad": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp],
+    "dg_conv3x3_wgrad_dense": [_vp, _i, _vp, _vp, _vp, _vp, _vp],
     "dg_gather_gemm": [C.POINTER(GGDesc), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_plan": [C.POINTER(ConvGeom), _i, C.POINTER(GGDesc)],
     "dg_last_conv_kernels": [],

@@ -21,6 +21,11 @@ struct WGArgs {
   int Mpix, ppb;
   int nci_t;
   float* db;       // IM2COL mode: bias gradient (column 18 of the im2col operand is the constant 1)
+  // dense-block mode of the wide kernel (dg_conv3x3_wgrad_dense): conv k = 1..nconv reads input tiles 0..k-1 of a shared slab and
+  // its adjoint is channel tile k-1 of the adjoint slab: only the (adjoint tile t, input tile <= t) pairs exist, and pair rows go
+  // to conv t+1's own gradient (row stride 9 * (t + 1) * 128) / bias gradient
+  int tri;
+  float* dwk[8]; float* dbk[8];
 };
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
@@ -639,9 +644,16 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
   const unsigned lin = gridDim.x <= 72 ? xcd_remap(lin0, gridDim.x * gridDim.y) : lin0;
   const int bx = (int)(lin % gridDim.x), by = (int)(lin / gridDim.x);
-  const int ci_t = bx % a.nci_t;
-  const int trow = (bx / a.nci_t) % 3;
-  const int co_t = bx / (a.nci_t * 3);
+  int ci_t = bx % a.nci_t;
+  int trow = (bx / a.nci_t) % 3;
+  int co_t = bx / (a.nci_t * 3);
+  if (a.tri) {                                  // bx = 3 * pair + tap row; pair p = t (t + 1) / 2 + input tile, input tile <= t
+    trow = bx % 3;
+    const int p = bx / 3;
+    co_t = 0;
+    while ((co_t + 1) * (co_t + 2) / 2 <= p) ++co_t;
+    ci_t = p - co_t * (co_t + 1) / 2;
+  }
   const int co0 = co_t * BCO, ci0 = ci_t * BCI;
   const int dr = trow - 1;
   const int pbeg = by * a.ppb;
@@ -736,7 +748,8 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
 
   // bias gradient (column sums of the adjoint) on the side: the workgroups of the centre tap row and first input-channel
   // tile already hold every adjoint fragment in registers; wave 0 adds them up (a lane's 8 values belong to one channel)
-  const bool do_db = a.db != nullptr && trow == 1 && ci_t == 0 && wave == 0;
+  float* const db_out = a.tri ? a.dbk[co_t] : (a.db ? a.db + co0 : nullptr);       // bias gradient of this adjoint tile's rows
+  const bool do_db = db_out != nullptr && trow == 1 && ci_t == 0 && wave == 0;
   float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
 
   issue(0, 0);
@@ -807,13 +820,16 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   if (do_db) {
 #pragma unroll
     for (int f = 0; f < 4; ++f)
-      if (co0 + 32 * f + r32 < a.Cout) atomicAdd(a.db + co0 + 32 * f + r32, dbacc[f]);
+      if (co0 + 32 * f + r32 < a.Cout) atomicAdd(db_out + 32 * f + r32, dbacc[f]);
   }
   // epilogue: one lane-constant 32-bit offset, everything else of an element's address is workgroup-uniform (scalar base)
-  const long long ldw = 9ll * a.Cin;
+  const int cin_w = a.tri ? (co_t + 1) * BCI : a.Cin;                  // input channels of the conv these rows belong to
+  const int cow0 = a.tri ? 0 : co0;                                    // first gradient row of this tile inside that conv
+  float* const dw_out = a.tri ? a.dwk[co_t] : a.dw;
+  const long long ldw = 9ll * cin_w;
   const int ci = ci0 + wave * 32 + r32;
-  const unsigned lane_off = (unsigned)((((long long)co0 + 4 * h) * ldw + ci) * 4);
-  const bool ci_ok = ci < a.Cin;
+  const unsigned lane_off = (unsigned)((((long long)cow0 + 4 * h) * ldw + ci) * 4);
+  const bool ci_ok = ci < cin_w;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     const int tap = trow * 3 + s;
@@ -822,7 +838,7 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int cor = 32 * f + (reg & 3) + 8 * (reg >> 2);             // + co0 + 4h
-        char* const base = reinterpret_cast<char*>(a.dw) + ((long long)cor * ldw + (long long)tap * a.Cin) * 4;
+        char* const base = reinterpret_cast<char*>(dw_out) + ((long long)cor * ldw + (long long)tap * cin_w) * 4;
         if (ci_ok && co0 + cor + 4 * h < a.Cout) atomicAdd(reinterpret_cast<float*>(base + lane_off), acc[s][f][reg]);
       }
   }
@@ -833,8 +849,9 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
   constexpr int BCO = 128, BCI = 128;
   const int nco_t = (a.Cout + BCO - 1) / BCO;
   a.nci_t = (a.Cin + BCI - 1) / BCI;
-  const int ntiles = nco_t * 3 * a.nci_t;
-  const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
+  const int npairs = a.tri ? nco_t * (nco_t + 1) / 2 : nco_t * a.nci_t;            // dense-block mode: input tile <= adjoint tile
+  const int ntiles = 3 * npairs;
+  const double flops = 2.0 * 9 * BCO * (double)BCI * npairs * a.Mpix;
   const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
   static const int tb_env = getenv("DG_WG_TB") ? atoi(getenv("DG_WG_TB")) : 1536;
   const int splits = wg_pick_splits(ntiles, tb_env, cap, a.Mpix, &a.ppb);           // 3 rounds of 512 slots (2 per CU)
@@ -898,4 +915,32 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
   if (rows) return g->dtype == DG_F32 ? wg3_launch<float>(a, st) : wg3_launch<bf16_t>(a, st);
   if (wide_s2) return wg3w_launch<true>(a, st);
   return g->dtype == DG_F32 ? wg_launch<float>(a, st) : wg_launch<bf16_t>(a, st);
+}
+
+// Weight (and bias) gradients of ALL convs of a dense block in one launch (generator.py:14-41: conv k reads slab channels
+// [0, k * 128) and writes 128 channels).  x = the block's activation slab [N, H, W, nconv * 128], dy = its adjoint slab (channels
+// [(k - 1) * 128, k * 128) = the adjoint of conv k's output); dw[k - 1] / db[k - 1] = conv k's fp32 gradients ([128][9][k * 128] /
+// [128], accumulated into).  Five separate launches give the first convs 3 tiles each: their split-K leaves 196 KB of atomics per
+// 100 MFLOP (766-875 TFLOP/s); the 15 (adjoint tile, input tile) pairs of a block in one grid have 15x longer pixel ranges per
+// workgroup.  bf16, stride 1, 128 channels per conv, rows of a multiple of 32 pixels.
+extern "C" int dg_conv3x3_wgrad_dense(const dg_conv_geom* g, int nconv, const void* x, const void* dy, float* const* dw,
+                                      float* const* db, void* stream) {
+  if (!g || !x || !dy || !dw) return DG_ERR_BAD_ARG;
+  if (g->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  if (nconv < 1 || nconv > 8 || g->N <= 0 || g->H <= 0 || g->W <= 0 || g->stride != 1 || g->pixel_shuffle || g->W % 32) return DG_ERR_BAD_SHAPE;
+  if (g->Cin != nconv * 128 || g->Cout != nconv * 128 || g->ldx % 8 || g->ldy % 8 || g->ldx < g->Cin || g->ldy < g->Cout) return DG_ERR_BAD_SHAPE;
+  for (int k = 0; k < nconv; ++k)
+    if (!dw[k]) return DG_ERR_BAD_ARG;
+  WGArgs a{};
+  a.x = x; a.u = dy; a.dw = dw[0]; a.ldx = g->ldx; a.ldu = g->ldy;
+  a.H = g->H; a.W = g->W; a.stride = 1; a.Ho = g->H; a.Wo = g->W;
+  a.Cin = g->Cin; a.Cout = g->Cout;
+  a.u_ps = 0; a.cps_chunks = 1;
+  const long long mp = (long long)g->N * a.Ho * a.Wo;
+  if (mp >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
+  a.Mpix = (int)mp;
+  a.db = nullptr;
+  a.tri = 1;
+  for (int k = 0; k < nconv; ++k) { a.dwk[k] = dw[k]; a.dbk[k] = db ? db[k] : nullptr; }
+  return wg3w_launch<false>(a, reinterpret_cast<hipStream_t>(stream));
 }

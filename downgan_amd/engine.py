@@ -664,12 +664,12 @@ class NativeGenerator:
                 slab, us, gx = self._saved[d], bw["us"][d & 1], bw["gx"][d & 1]
                 pre = f"res_blocks.{i}.dense_blocks.{j}.b"
                 o.axpby(us[..., 4 * F_:], go, RES_SCALE)
-                o.conv_wgrad(self.cv_b[4], slab, us[..., 4 * F_:], GW(f"{pre}5.0"), db=GB(f"{pre}5.0"))
                 for k in range(4, 0, -1):
                     # u_k = LeakyReLU'(b_k) * sum_{m > k} W_m[:, slice k]^T (*) u_m: one data gradient over u_{k+1..5}
                     uk = us[..., (k - 1) * F_:k * F_]
                     o.conv_dgrad(self.cv_v[k], us[..., k * F_:], self.vpack(d, k), uk, mask=slab[..., k * F_:(k + 1) * F_], mask_slope=G_SLOPE)
-                    o.conv_wgrad(self.cv_b[k - 1], slab[..., :k * F_], uk, GW(f"{pre}{k}.0"), db=GB(f"{pre}{k}.0"))
+                # the block's five weight / bias gradients, wgrad(slab[:kF], u_k): one launch over the 15 (u tile, slab tile) pairs
+                o.conv_wgrad_dense(self.cv_b, slab, us, [GW(f"{pre}{k}.0") for k in range(1, 6)], [GB(f"{pre}{k}.0") for k in range(1, 6)])
                 # d x_drb = sum_m W_m[:, slice 0]^T (*) u_m + d o (identity path of o = 0.2*b5 + x) = d o of the previous dense block
                 o.conv_dgrad(self.cv_v[0], us, self.vpack(d, 0), gx, r1=go, s1=1.0)
                 go = gx

@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import dataclasses
 
+import os
 import torch
 
 from . import _lib
@@ -289,6 +290,31 @@ class HipOps:
         g = self._geom(cv, pix_layout(x)[0], pix_layout(dy)[0])
         check(self._timed("conv_wgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad(
             C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), self._stream()), self.conv_bytes(cv), cv.net, self._geom_tag(cv)), "dg_conv3x3_wgrad")
+
+    def conv_wgrad_dense(self, cvs, slab, us, dws, dbs):
+        """Weight / bias gradients of all convs of a dense block: conv k (``cvs[k-1]``: k*F -> F channels) reads ``slab[..., :k*F]``,
+        its adjoint is ``us[..., (k-1)*F:k*F]``; ``dws`` / ``dbs`` = their flat fp32 gradients.  One launch when the wide kernel
+        takes the shape (bf16, F = 128, rows of a multiple of 32 pixels), else one launch per conv."""
+        n, F_ = len(cvs), cvs[0].Cout
+        cv0 = cvs[0]
+        if not (self.dtype == "bf16" and F_ == 128 and cv0.W % 32 == 0 and all(c.Cin == (k + 1) * F_ and c.Cout == F_ and c.stride == 1 and not c.pixel_shuffle
+                                                                              for k, c in enumerate(cvs))) or os.environ.get("DG_WG_NODENSE"):
+            for k, c in enumerate(cvs):
+                self.conv_wgrad(c, slab[..., :(k + 1) * F_], us[..., k * F_:(k + 1) * F_], dws[k], db=dbs[k])
+            return
+        self._act(slab); self._act(us)
+        assert tuple(slab.shape) == (cv0.N, cv0.H, cv0.W, n * F_) and tuple(us.shape) == tuple(slab.shape)
+        for k in range(n):
+            assert dws[k].dtype == torch.float32 and dws[k].numel() == F_ * 9 * (k + 1) * F_ and dws[k].is_contiguous()
+            assert dbs[k].dtype == torch.float32 and dbs[k].numel() >= F_
+        cvv = Conv(cv0.N, cv0.H, cv0.W, n * F_, n * F_, net=cv0.net)
+        g = self._geom(cvv, pix_layout(slab)[0], pix_layout(us)[0])
+        pw = (C.c_void_p * n)(*[t.data_ptr() for t in dws])
+        pb = (C.c_void_p * n)(*[t.data_ptr() for t in dbs])
+        flops = sum(self.conv_flops(c) for c in cvs)
+        nbytes = sum(self.conv_bytes(c) for c in cvs)
+        check(self._timed("conv_wgrad", flops, lambda: self.lib.dg_conv3x3_wgrad_dense(
+            C.byref(g), n, _ptr(slab), _ptr(us), pw, pb, self._stream()), nbytes, cv0.net, f"dense{n}x{F_}@{cv0.H}"), "dg_conv3x3_wgrad_dense")
 
     def colsum(self, dy, db):
         """db[c] += sum over all pixels/rows of dy[..., c]; dy is NHWC (any dtype of {fp32, compute}) or 2-D."""

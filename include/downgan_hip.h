@@ -130,7 +130,13 @@ int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, const void* d
  * weight-gradient of nn.Conv2d (wasserstein.py:52,80) and, with (x:=tangent, dy:=adjoint), the
  * double-backward term of the gradient penalty (wasserstein.py:100-117 under :52). */
 int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void* dy, float* dw, float* db,
-                     void* stream);   /* db (optional): bias gradient += sum_pixels dy */
+                     void* stream); /* Weight and bias gradients of ALL convs of a dense block (generator.py:14-41) in one launch.  Conv k = 1..nconv reads channels
+ * [0, k*128) of the block's activation slab x [N,H,W,nconv*128] and its output adjoint is channels [(k-1)*128, k*128) of the
+ * adjoint slab dy; dw[k-1] ([128][9][k*128] fp32) and db[k-1] ([128] fp32, db or any entry may be NULL) are accumulated into.
+ * g: Cin = Cout = nconv*128, stride 1, ldx / ldy = pixel strides of the two slabs; bf16; W % 32 == 0. */
+int dg_conv3x3_wgrad_dense(const dg_conv_geom* g, int nconv, const void* x, const void* dy,
+                           float* const* dw, float* const* db, void* stream);
+  /* db (optional): bias gradient += sum_pixels dy */
 
 /* db[c] (fp32) += sum over rows of dy[row, c]  (bias gradient of a conv or Linear).  Row r is at
  * element offset (r / rows_inner)*ld_outer + (r % rows_inner)*ld, so one sub-position of a

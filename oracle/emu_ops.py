@@ -224,6 +224,11 @@ class EmuOps:
                 patch = xp[:, r:r + st * cv.Ho:st, s:s + st * cv.Wo:st, :]
                 g[:, r * 3 + s, :] += torch.einsum("nhwo,nhwc->oc", u, patch)
 
+    def conv_wgrad_dense(self, cvs, slab, us, dws, dbs):
+        F_ = cvs[0].Cout
+        for k, c in enumerate(cvs):
+            self.conv_wgrad(c, slab[..., :(k + 1) * F_], us[..., k * F_:(k + 1) * F_], dws[k], db=dbs[k])
+
     def colsum(self, dy, db):
         Cc = dy.shape[-1]
         db[:Cc] += dy.float().reshape(-1, Cc).sum(0)

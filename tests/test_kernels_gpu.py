@@ -140,6 +140,31 @@ def test_conv_wgrad(dtype, cfg):
         assert (db.cpu() - db_ref).abs().max().item() <= tol * 8 * float(db_ref.abs().max()), cfg
 
 
+@pytest.mark.parametrize("N,H,W,n", [(2, 32, 32, 5), (1, 16, 64, 3), (1, 8, 32, 1)])
+def test_conv_wgrad_dense_block(N, H, W, n):
+    """dg_conv3x3_wgrad_dense: the weight / bias gradients of all convs of a dense block (conv k: k*128 -> 128 channels on a shared
+    slab, adjoints stacked in a second slab) in one launch == one dg_conv3x3_wgrad per conv == the oracle."""
+    hip, emu = pair("bf16")
+    g = torch.Generator().manual_seed(21)
+    F = 128
+    slab = rnd((N, H, W, n * F), emu.tdtype, g)
+    us = rnd((N, H, W, n * F), emu.tdtype, g)
+    cvs = [Conv(N, H, W, (k + 1) * F, F) for k in range(n)]
+    dws_ref = [torch.randn(F * 9 * (k + 1) * F, generator=g) for k in range(n)]
+    dbs_ref = [torch.randn(F, generator=g) for _ in range(n)]
+    dws = [t.clone().cuda() for t in dws_ref]; dbs = [t.clone().cuda() for t in dbs_ref]
+    dws1 = [t.clone().cuda() for t in dws_ref]; dbs1 = [t.clone().cuda() for t in dbs_ref]
+    emu.conv_wgrad_dense(cvs, slab, us, dws_ref, dbs_ref)
+    hip.conv_wgrad_dense(cvs, slab.cuda(), us.cuda(), dws, dbs)
+    assert hip.lib.dg_last_conv_kernels is not None
+    for k in range(n):
+        hip.conv_wgrad(cvs[k], slab.cuda()[..., :(k + 1) * F], us.cuda()[..., k * F:(k + 1) * F], dws1[k], db=dbs1[k])
+        scale = float(dws_ref[k].abs().max())
+        assert (dws[k].cpu() - dws_ref[k]).abs().max().item() <= 8e-4 * scale, k
+        assert (dws[k] - dws1[k]).abs().max().item() <= 1e-4 * scale, k
+        assert (dbs[k].cpu() - dbs_ref[k]).abs().max().item() <= 8e-4 * float(dbs_ref[k].abs().max()), k
+
+
 def test_conv_slab_views_f32():
     """channel-slice views of a wider slab as input and output (dense-block layout)."""
     hip, emu = pair("f32")
