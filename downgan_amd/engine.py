@@ -611,8 +611,8 @@ class NativeGenerator:
             hs = S << self.nup
             self._bwd = dict(
                 d_c30=o.zeros(B, hs, hs, F_), d_ups=[o.zeros(B, S << (u + 1), S << (u + 1), F_) for u in range(self.nup)],
-                d_trunk=o.zeros(B, S, S, F_), gy=[o.zeros(B, S, S, F_), o.zeros(B, S, S, F_)], go=o.zeros(B, S, S, F_),
-                gx=[o.zeros(B, S, S, F_), o.zeros(B, S, S, F_)], us=[o.zeros(B, S, S, 5 * F_), o.zeros(B, S, S, 5 * F_)])
+                d_trunk=o.zeros(B, S, S, F_), gy=[o.zeros(B, S, S, F_), o.zeros(B, S, S, F_)],
+                gx=o.zeros(B, S, S, F_), us=[o.zeros(B, S, S, 5 * F_), o.zeros(B, S, S, 5 * F_)])
         bw = self._bwd
         W = lambda n: P.w(n + ".weight")
         WD = lambda n: P.wd(n + ".weight")
@@ -655,26 +655,27 @@ class NativeGenerator:
         o.conv_dgrad(self.cv_conv2, d_trunk, WD("conv2"), gy)
         gyi = 0
         for i in range(self.nrb - 1, -1, -1):
-            # RRDB i: y = 0.2*o_{3i+2} + x_rrdb
-            go = bw["go"]
-            o.axpby(go, gy, RES_SCALE)                    # d o_{3i+2}
+            # RRDB i: y = 0.2*o_{3i+2} + x_rrdb, so d o_{3i+2} = 0.2 * d y.  What travels from block to block is u5 = 0.2 * d o (the
+            # adjoint of conv 5's output, o = 0.2*b5 + x), written by the PREVIOUS block's last data gradient straight into this
+            # block's adjoint slab: no separate scaling pass per block.
+            o.axpby(bw["us"][(3 * i + 2) & 1][..., 4 * F_:], gy, RES_SCALE * RES_SCALE)
             for j in (2, 1, 0):
                 d = 3 * i + j
-                # adjoint slab: channels [(k-1)F, kF) = u_k, the adjoint of conv k's output (k = 1..5); u_5 = 0.2 * d o
-                slab, us, gx = self._saved[d], bw["us"][d & 1], bw["gx"][d & 1]
+                # adjoint slab: channels [(k-1)F, kF) = u_k, the adjoint of conv k's output (k = 1..5)
+                slab, us = self._saved[d], bw["us"][d & 1]
                 pre = f"res_blocks.{i}.dense_blocks.{j}.b"
-                o.axpby(us[..., 4 * F_:], go, RES_SCALE)
                 for k in range(4, 0, -1):
                     # u_k = LeakyReLU'(b_k) * sum_{m > k} W_m[:, slice k]^T (*) u_m: one data gradient over u_{k+1..5}
                     uk = us[..., (k - 1) * F_:k * F_]
                     o.conv_dgrad(self.cv_v[k], us[..., k * F_:], self.vpack(d, k), uk, mask=slab[..., k * F_:(k + 1) * F_], mask_slope=G_SLOPE)
                 # the block's five weight / bias gradients, wgrad(slab[:kF], u_k): one launch over the 15 (u tile, slab tile) pairs
                 o.conv_wgrad_dense(self.cv_b, slab, us, [GW(f"{pre}{k}.0") for k in range(1, 6)], [GB(f"{pre}{k}.0") for k in range(1, 6)])
-                # d x_drb = sum_m W_m[:, slice 0]^T (*) u_m + d o (identity path of o = 0.2*b5 + x) = d o of the previous dense block
-                o.conv_dgrad(self.cv_v[0], us, self.vpack(d, 0), gx, r1=go, s1=1.0)
-                go = gx
+                # d x_drb = sum_m W_m[:, slice 0]^T (*) u_m + d o (identity path) = d o of the previous dense block; stored as that
+                # block's u5 = 0.2 * (sum + d o) = 0.2 * sum + this block's u5
+                nxt = bw["us"][(d - 1) & 1][..., 4 * F_:] if j > 0 else bw["gx"]
+                o.conv_dgrad(self.cv_v[0], us, self.vpack(d, 0), nxt, r1=us[..., 4 * F_:], s1=RES_SCALE)
             gyn = bw["gy"][gyi ^ 1]
-            o.axpby(gyn, go, 1.0, gy, 1.0)                # d x_rrdb = d x_drb(3i) + d y (identity path)
+            o.axpby(gyn, bw["gx"], 1.0 / RES_SCALE, gy, 1.0)   # d x_rrdb = d x_drb(3i) + d y (identity path); gx holds 0.2 * d x_drb
             gy, gyi = gyn, gyi ^ 1
         # conv1: d out1 = trunk-path gradient + skip gradient
         o.axpby(gy, gy, 1.0, d_trunk, 1.0)
