@@ -322,7 +322,9 @@ def main():
                        "executed_padded_tflop_per_sample_step": round(w_padded / 1e12, 4),
                        "work": "1.4*Gf + 10.4*Cf per sample-step, real channels (SURVEY 8(d) counts 1.6*Gf: the generator iteration's "
                                "G(coarse) is the critic iteration's, computed once)",
-                       "generator_steps_in_timed_region": gen_steps_timed},
+                       "generator_steps_in_timed_region": gen_steps_timed,
+                       "critic_passes_stacked": bool(eng.stacked)},
+            "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             "step_mfma_frac": round(w_step * value / world / 1e12 / MFMA_PEAK_TFLOPS["bf16" if is_f8 else args.dtype], 4),
             "losses": {k: scal[k] for k in ("critic_loss", "gp_ret", "g_loss") if k in scal},
             "roofline": roofline, "critic_conv_stack": critic_stack, "kernels": kernels,

@@ -173,7 +173,7 @@ class NativeCritic:
 
     STRIDES = (1, 2, 1, 2, 1, 2, 1, 2)
 
-    def __init__(self, ops, coarse_dim, fine_dim, nc, batch):
+    def __init__(self, ops, coarse_dim, fine_dim, nc, batch, stacked=False):
         assert fine_dim % 16 == 0, "critic.py:95 needs fine_dim divisible by 16"
         self.ops, self.B = ops, batch
         self.cd, self.fine, self.nc = coarse_dim, fine_dim, nc
@@ -201,18 +201,33 @@ class NativeCritic:
         P.finalize()
         # activations / adjoints / tangents
         o = ops
-        self.acts = [o.zeros(*o.out_shape(cv)) for cv in self.convs]
-        self.us = [o.zeros(*o.out_shape(cv)) for cv in self.convs]
         # 1-bit LeakyReLU' masks beside the activations (dg_epilogue.mask_bits / out_bits): the data-gradient and
         # tangent-forward epilogues are HBM-bound and the mask would otherwise be a full re-read of the activation.
         # Needs 64-channel wave tiles, i.e. every conv width >= 128 (cfg2: yes; the 16-filter configs keep plain masks).
         use_bits = os.environ.get("DG_NO_MASK_BITS") is None and all(c >= 128 and c % 64 == 0 for c in self.c_pad[1:])
-        self.act_bits = [o.zeros(*o.bits_shape(a.shape), dtype=torch.int16) for a in self.acts] if use_bits else None
-        self.h1pre = o.zeros(batch, FC_HID_LD, dtype=torch.float32)
-        self.h1 = o.zeros(batch, FC_HID_LD)
-        self.outpre = o.zeros(batch, FC_OUT_P, dtype=torch.float32)
-        self.out = o.zeros(batch, FC_OUT_P, dtype=torch.float32)
-        self.dout = o.zeros(batch, FC_OUT_P, dtype=torch.float32)
+        self.f8 = bool(getattr(o, "f8", False))
+        # STACKED passes (critic_iteration_stacked): the real, the generated and the interpolated batch of a critic iteration go
+        # through the layers as ONE batch of 3B -- a third of the launches, each three times as long (the conv kernels gain 4-9 %
+        # forward, 1-3 % backward from the longer grids) -- so every per-sample buffer holds 3B samples; the single-pass methods
+        # below work on the first B.  Needs the bit masks (the tangent pass reads a row range of them), the fused FC1 gradient and,
+        # for the memory (3 x 40 GB of activations + adjoints at cfg2), no fp8 copies.
+        self.stacked = bool(stacked) and use_bits and not self.f8 and 3 * batch <= 128 and os.environ.get("DG_NO_FC1_FUSED") is None
+        cap = 3 * batch if self.stacked else batch
+        self.cap = cap
+        full = lambda cv: (cap,) + tuple(o.out_shape(cv))[1:]
+        self._acts_all = [o.zeros(*full(cv)) for cv in self.convs[:7]] + [None]
+        self._us_all = [o.zeros(*full(cv)) for cv in self.convs]
+        self._bits_all = [o.zeros(*o.bits_shape(full(cv)), dtype=torch.int16) for cv in self.convs] if use_bits else None
+        self.acts = [a[:batch] if a is not None else o.zeros(*o.out_shape(self.convs[7])) for a in self._acts_all]
+        self.us = [u[:batch] for u in self._us_all]
+        self.act_bits = [b[:batch] for b in self._bits_all] if use_bits else None
+        self._h1pre_all = o.zeros(cap, FC_HID_LD, dtype=torch.float32)
+        self._h1_all = o.zeros(cap, FC_HID_LD)
+        self._outpre_all = o.zeros(cap, FC_OUT_P, dtype=torch.float32)
+        self._out_all = o.zeros(cap, FC_OUT_P, dtype=torch.float32)
+        self._dout_all = o.zeros(cap, FC_OUT_P, dtype=torch.float32)
+        self.h1pre, self.h1, self.outpre = self._h1pre_all[:batch], self._h1_all[:batch], self._outpre_all[:batch]
+        self.out, self.dout = self._out_all[:batch], self._dout_all[:batch]
         self.uh1 = o.zeros(batch, FC_HID_LD, dtype=torch.float32)
         self._tan = None
         # FC1's weight gradient (1.9 GB fp32 at cfg2) is formed ONCE per critic iteration from the rows of all three passes
@@ -223,10 +238,11 @@ class NativeCritic:
             self._y7_all = o.zeros(4 * batch, *self.acts[7].shape[1:])
             self._uh1_all = o.zeros(3 * batch, FC_HID_LD, dtype=torch.float32)
             self.acts[7] = self._y7_all[3 * batch:]
+            if self.stacked:
+                self._acts_all[7] = self._y7_all[:3 * batch]     # a stacked forward leaves FC1's rows in slots 0-2 directly
         # fp8 mode (BASELINE configs[4]): MXFP8 forms of every tensor an fp8 conv reads -- activations act[l-1] (forward of
         # layer l), adjoints us[l] (data gradient of layer l), the penalty's tangents, both weight packs -- written by the
         # PRODUCING launch's epilogue (dg_epilogue.out_q) or, for the weights, once per optimizer step; None = not needed
-        self.f8 = bool(getattr(o, "f8", False))
         qbuf = lambda t: (o.zeros(*t.shape, dtype=torch.uint8), o.zeros(*t.shape[:-1], t.shape[-1] // 32, dtype=torch.uint8))
         self.actq = [None] * 8
         self.usq = [None] * 8
@@ -366,44 +382,114 @@ class NativeCritic:
         o, P = self.ops, self.P
         self.forward(xhat)
         self.backward(xhat, 1.0, wgrad=False, dx=g_buf, fc1_slot=fc1_slot)
+        self.gp_tangent(g_buf, v_buf, ss, coef, gp_scalar, hp, b_global, 0, fc1_slot)
+
+    def gp_tangent(self, g_buf, v_buf, ss, coef, gp_scalar, hp: HyperParams, b_global, r0, fc1_slot):
+        """Second half of the penalty (after g = dC/dx-hat is in ``g_buf``): norm, v0 = dGP/dg, tangent forward and the
+        penalty's weight gradients.  ``r0``: first sample of the x-hat pass in the per-sample buffers (0, or 2B when stacked)."""
+        o, P, B = self.ops, self.P, self.B
+        rows = slice(r0, r0 + B)
+        us = [u[rows] for u in self._us_all]
+        bits = [b[rows] for b in self._bits_all] if self._bits_all is not None else None
+        acts = self.acts if r0 == 0 else [a[rows] for a in self._acts_all]      # (masks of the 16-filter configs; r0 = 0 there)
+        h1 = self._h1_all[rows]
+        uh1 = self.uh1 if fc1_slot is None else self._uh1_all[fc1_slot * B:(fc1_slot + 1) * B]
         ss.zero_()
         o.sumsq_rows(g_buf, ss)
-        o.gp_finish(ss, self.B, b_global, hp.gp_lambda, hp.gp_lambda, coef, gp_scalar)
+        o.gp_finish(ss, B, b_global, hp.gp_lambda, hp.gp_lambda, coef, gp_scalar)
         o.scale_rows(g_buf, coef, v_buf)
         if self._tan is None:
             big = max(a.numel() for a in self.acts)
             self._tan = [o.zeros(big), o.zeros(big)]
-            self._th1pre = o.zeros(self.B, FC_HID_LD, dtype=torch.float32)
-            self._th1 = o.zeros(self.B, FC_HID_LD)
-            self._ones = o.zeros(self.B, FC_OUT_P, dtype=torch.float32)
+            self._th1pre = o.zeros(B, FC_HID_LD, dtype=torch.float32)
+            self._th1 = o.zeros(B, FC_HID_LD)
+            self._ones = o.zeros(B, FC_OUT_P, dtype=torch.float32)
             o.fill_col(self._ones, 0, 1.0)
             if self.f8:
                 self._tanq = [(o.zeros(big, dtype=torch.uint8), o.zeros(big // 32, dtype=torch.uint8)) for _ in range(2)]
         t, tq = v_buf, None
         for l, cv in enumerate(self.convs):
             name = f"features.{2 * l}.weight"
-            o.conv_wgrad(cv, t, self.us[l], P.grad(name).reshape(-1))
+            o.conv_wgrad(cv, t, us[l], P.grad(name).reshape(-1))
             tn = self._tan[l & 1][:self.acts[l].numel()].view(self.acts[l].shape)
             if l == 7 and fc1_slot is not None:           # FC1's tangent input rows stay for fc1_flush
-                tn = self._y7_all[fc1_slot * self.B:(fc1_slot + 1) * self.B]
+                tn = self._y7_all[fc1_slot * B:(fc1_slot + 1) * B]
             f8kw, tqn = {}, None
             if self.f8:
                 if self.actq[l] is not None:          # the next layer's tangent forward is an fp8 conv
                     n, sh = self.acts[l].numel(), self.acts[l].shape
                     tqn = (self._tanq[l & 1][0][:n].view(sh), self._tanq[l & 1][1][:n // 32].view(*sh[:-1], sh[-1] // 32))
                 f8kw = dict(xq=tq, wq=self.wq_f[l], out_q=tqn)
-            if self.act_bits:
-                o.conv_fwd(cv, t, P.w(name), tn, mask_bits=self.act_bits[l], mask_slope=C_SLOPE, **f8kw)
+            if bits:
+                o.conv_fwd(cv, t, P.w(name), tn, mask_bits=bits[l], mask_slope=C_SLOPE, **f8kw)
             else:
-                o.conv_fwd(cv, t, P.w(name), tn, mask=self.acts[l], mask_slope=C_SLOPE, **f8kw)
+                o.conv_fwd(cv, t, P.w(name), tn, mask=acts[l], mask_slope=C_SLOPE, **f8kw)
             t, tq = tn, tqn
-        t7 = t.view(self.B, self.fc_k)
+        t7 = t.view(B, self.fc_k)
         if fc1_slot is None:
-            o.linear_dw(self.uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
+            o.linear_dw(uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
         self._th1pre.zero_()
         o.linear_fwd(t7, P.w2d("classifier.0.weight"), self._th1pre, o_real=FC_HID, net="C")
-        o.bias_act(self._th1pre, None, self._th1, mask=self.h1, mask_slope=C_SLOPE)
+        o.bias_act(self._th1pre, None, self._th1, mask=h1, mask_slope=C_SLOPE)
         o.linear_dw(self._ones, self._th1, P.grad("classifier.2.weight"), o_real=1, net="C")
+
+    # ---- stacked passes: real | fake | x-hat as one batch of 3B (see __init__) ------------------------------------------
+    def _cvn(self, n):
+        if n not in self._cv_cache:
+            self._cv_cache[n] = [dataclasses.replace(cv, N=n) for cv in self.convs]
+        return self._cv_cache[n]
+
+    _cv_cache = None
+
+    def forward_stacked(self, x3):
+        """critic.py:101-106 on x3 = [real | fake | x-hat] (3B samples, compact or padded NHWC).  Returns out[3B, .] (fp32)."""
+        o, P, B = self.ops, self.P, self.B
+        if self._cv_cache is None:
+            self._cv_cache = {}
+        cur = x3
+        for l, cv in enumerate(self._cvn(3 * B)):
+            o.conv_fwd(cv, cur, P.w(f"features.{2 * l}.weight"), self._acts_all[l],
+                       bias=P.master("features.0.bias") if l == 0 else None, act=C_SLOPE, out_bits=self._bits_all[l])
+            cur = self._acts_all[l]
+        y7 = self._acts_all[7].view(3 * B, self.fc_k)
+        self._h1pre_all.zero_()
+        for p in range(3):                                # the split-K FC1 kernel takes up to 32 rows per call
+            rows = slice(p * B, (p + 1) * B)
+            o.linear_fwd(y7[rows], P.w2d("classifier.0.weight"), self._h1pre_all[rows], o_real=FC_HID, net="C")
+        o.bias_act(self._h1pre_all, P.master("classifier.0.bias"), self._h1_all, act=C_SLOPE)
+        self._outpre_all.zero_()
+        for p in range(3):
+            rows = slice(p * B, (p + 1) * B)
+            o.linear_fwd(self._h1_all[rows], P.w2d("classifier.2.weight"), self._outpre_all[rows], o_real=1, net="C")
+        o.bias_act(self._outpre_all, P.master("classifier.2.bias"), self._out_all)
+        return self._out_all
+
+    def backward_stacked(self, x3, dout_values, dx):
+        """Adjoint chain of forward_stacked: d out_b = dout_values[pass of b]; parameter gradients from the first TWO passes
+        (wasserstein.py:52: the real and the generated batch; FC1's is left to fc1_flush), ``dx`` = input gradient of the THIRD
+        (wasserstein.py:100-106: g = dC/dx-hat, whose adjoints stay in rows [2B, 3B) for the tangent pass)."""
+        o, P, B = self.ops, self.P, self.B
+        n3, w2 = 3 * B, slice(0, 2 * B)
+        dout, uh1, h1 = self._dout_all, self._uh1_all, self._h1_all
+        dout.zero_()
+        for p in range(3):
+            o.fill_col(dout[p * B:(p + 1) * B], 0, dout_values[p])
+        y7 = self._acts_all[7].view(n3, self.fc_k)
+        o.linear_dw(dout[w2], h1[w2], P.grad("classifier.2.weight"), o_real=1, net="C")
+        o.colsum(dout[w2], P.grad("classifier.2.bias"))
+        o.linear_dx(dout, P.w2d("classifier.2.weight"), uh1, mask=h1, mask_slope=C_SLOPE, o_real=1, net="C")
+        o.colsum(uh1[w2], P.grad("classifier.0.bias"))
+        o.linear_dx(uh1[:, :FC_HID_P], P.w2d("classifier.0.weight"), self._us_all[7].view(n3, self.fc_k),
+                    mask=y7, mask_slope=C_SLOPE, o_real=FC_HID, net="C")
+        cv3, cv2, cv1 = self._cvn(n3), self._cvn(2 * B), self.convs
+        for l in range(7, -1, -1):
+            name = f"features.{2 * l}.weight"
+            xin = self._acts_all[l - 1] if l > 0 else x3
+            o.conv_wgrad(cv2[l], xin[w2], self._us_all[l][w2], P.grad(name).reshape(-1), db=P.grad("features.0.bias") if l == 0 else None)
+            if l > 0:
+                o.conv_dgrad(cv3[l], self._us_all[l], P.wd(name), self._us_all[l - 1], mask_bits=self._bits_all[l - 1], mask_slope=C_SLOPE)
+            else:
+                o.conv_dgrad(cv1[0], self._us_all[0][2 * B:], P.wd(name), dx)
 
 
 # =============================================================================================== generator
@@ -696,14 +782,22 @@ class TrainEngine:
     SCALARS = ("c_real_mean", "c_fake_mean", "gp_ret", "g_c_fake_mean", "l1_sum")
 
     def __init__(self, ops, coarse_side, filters, channels, batch, hp: HyperParams = None, n_predictands=2,
-                 num_res_blocks=16, num_upsample=3, dist=None):
+                 num_res_blocks=16, num_upsample=3, dist=None, stacked=None):
         self.ops, self.hp = ops, hp or HyperParams()
         self.B, self.S = batch, coarse_side
         self.dist = dist
         self.world = dist.world_size if dist is not None else 1
         fine = coarse_side << num_upsample
         self.G = NativeGenerator(ops, filters, channels, batch, coarse_side, n_predictands, num_res_blocks, num_upsample)
-        self.C = NativeCritic(ops, filters, fine, n_predictands, batch)
+        # compact 2-channel fields (below) and, on top of them, the three critic passes of an iteration stacked into one batch
+        compact2 = n_predictands <= 2 and fine % 32 == 0 and not any(
+            os.environ.get(k) is not None for k in ("DG_NO_COMPACT2", "DG_WG_NOIM2COL", "DG_GG_NOIM2COL"))
+        # OPT-IN (stacked=True / DG_STACKED=1): measured +0.4-0.6 % per step at cfg2 for +77 GiB of HBM, and the
+        # data-parallel overlap of the generator's gradient exchange with the real-batch pass goes away
+        if stacked is None:
+            stacked = os.environ.get("DG_STACKED") is not None
+        stacked = stacked and compact2 and self._fits_stacked(ops, filters, batch, coarse_side, fine, num_res_blocks)
+        self.C = NativeCritic(ops, filters, fine, n_predictands, batch, stacked=stacked)
         assert self.C.c_pad[0] == self.G.np_p
         o = ops
         # Fields of the fine grid are stored np_p (16) channels wide like every activation.  With <= 2 predictands the critic's
@@ -713,14 +807,17 @@ class TrainEngine:
         # also leaves compact copies of its two inputs (the real and the generated batch) for their own critic passes.
         self.fine_shape = (batch, fine, fine, self.G.np_p)
         # (the weight-gradient kernel that takes the compact form needs rows of a multiple of 32 pixels)
-        self.compact2 = bool(self.C.convs[0].cin_real) and fine % 32 == 0 and not any(
-            os.environ.get(k) is not None for k in ("DG_NO_COMPACT2", "DG_WG_NOIM2COL", "DG_GG_NOIM2COL"))
+        self.compact2 = compact2 and bool(self.C.convs[0].cin_real)
+        self.stacked = self.C.stacked and self.compact2
         cshape = (batch, fine, fine, 2) if self.compact2 else self.fine_shape
-        self.xhat = o.zeros(*cshape)
         self.gbuf = o.zeros(*self.fine_shape)
         self.vbuf = o.zeros(*cshape)
-        self.real_c = o.zeros(*cshape) if self.compact2 else None
-        self.fake_c = o.zeros(*cshape) if self.compact2 else None
+        if self.compact2:      # one buffer [real | fake | x-hat]: the stacked critic pass reads it as a batch of 3B
+            self.x3 = o.zeros(3 * batch, fine, fine, 2)
+            self.real_c, self.fake_c, self.xhat = self.x3[:batch], self.x3[batch:2 * batch], self.x3[2 * batch:]
+        else:
+            self.x3 = self.real_c = self.fake_c = None
+            self.xhat = o.zeros(*cshape)
         self.dfake = None
         self.ss = o.zeros(batch, dtype=torch.float32)
         self.coef = o.zeros(batch, dtype=torch.float32)
@@ -733,6 +830,23 @@ class TrainEngine:
     def _sc(self, name):
         i = self.SCALARS.index(name)
         return self.scal[i:i + 1]
+
+    @staticmethod
+    def _fits_stacked(ops, filters, batch, coarse_side, fine, nrb):
+        """Is there HBM for the stacked critic passes (3B samples of activations + adjoints) beside everything else?  A rough
+        upper estimate of the whole engine's footprint against the device (cfg2: ~225 of 288 GB)."""
+        if not torch.cuda.is_available() or getattr(ops, "device", None) is None or torch.device(ops.device).type != "cuda":
+            return True                                    # CPU emulation (tests): no budget to respect
+        es = 4 if ops.tdtype == torch.float32 else 2
+        cd, h, per_c = filters, fine, 0
+        for l, st in enumerate(NativeCritic.STRIDES):
+            h //= st
+            per_c += (cd << (l // 2)) * h * h              # channels cd, cd, 2cd, 2cd, 4cd, ... at the layer's output size
+        critic = 2 * 3 * batch * per_c * es * 1.07 + 2 * batch * cd * fine * fine * es + 24 * (cd * 8 * (fine // 16) ** 2 * 112 + 5e7 * (cd / 128.0) ** 2)
+        S, F_ = coarse_side, filters
+        gen = batch * es * ((3 * nrb + 1 + 4 + 2) * 5 * F_ * S * S + 6 * F_ * S * S + 5 * F_ * fine * fine + 2 * F_ * (fine * fine) // 3) + 24 * 1.1e8 * (F_ / 128.0) ** 2
+        total = torch.cuda.get_device_properties(ops.device).total_memory
+        return critic + gen < 0.88 * total
 
     def _allreduce_and_step(self, P, defer=False):
         """Sum the flat gradient buffer over the ranks, then Adam.  Local gradients are already normalised by the GLOBAL
@@ -764,6 +878,8 @@ class TrainEngine:
         the previous generator iteration), the real-sample pass -- which needs no generator -- runs first and hides it."""
         o, hp, C, B = self.ops, self.hp, self.C, self.B
         bg = B * self.world
+        if self.stacked:
+            return self._critic_iteration_stacked(coarse, fine, alpha, apply_update, save_g)
         real_first = self.G.P._pending is not None
         xr = fine
         if not real_first:
@@ -789,6 +905,27 @@ class TrainEngine:
             C.fc1_flush()
         if apply_update:
             self._allreduce_and_step(C.P, defer=True)             # :52-55 (overlaps with the next generator forward)
+
+    def _critic_iteration_stacked(self, coarse, fine, alpha, apply_update, save_g):
+        """The same iteration with the real, generated and interpolated batch going through the critic as ONE batch of 3B
+        (NativeCritic.forward_stacked / backward_stacked): wasserstein.py:37, :38 and :97 are one forward; the backward of :52
+        through the first two and the autograd.grad of :100-106 through the third are one adjoint chain with per-pass d out."""
+        fake = self.G.forward(coarse, save=save_g)                                    # :35
+        self.ops.gp_interp(fine, fake, alpha, self.xhat, self.real_c, self.fake_c)    # :94 (+ the compact real / fake batches)
+        self._critic_passes_stacked(apply_update)
+
+    def _critic_passes_stacked(self, apply_update):
+        o, hp, C, B = self.ops, self.hp, self.C, self.B
+        bg = B * self.world
+        C.P.zero_grad(skip="classifier.0.weight")                                     # :43 (fc1_flush WRITES that gradient)
+        out = C.forward_stacked(self.x3)                                              # :37, :38, :97
+        o.sum_strided(out[:B], B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
+        o.sum_strided(out[B:2 * B], B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
+        C.backward_stacked(self.x3, (-1.0 / bg, 1.0 / bg, 1.0), self.gbuf)            # d(-mean c_real + mean c_fake), dC/dx-hat
+        C.gp_tangent(self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, 2 * B, 2)   # :40, :110-117
+        C.fc1_flush()
+        if apply_update:
+            self._allreduce_and_step(C.P, defer=True)                                 # :52-55
 
     def generator_iteration(self, coarse, fine, apply_update=True, reuse_fake=False):
         """wasserstein.py:58-83: g_loss = -mean(C(G(x)))*gamma + content_lambda*L1(G(x), y).
@@ -929,6 +1066,8 @@ class TrainEngineFS(TrainEngine):
         o.lowpass5(fake, high=self.fake_high)                     # :37,40
         o.lowpass5(fine, high=self.real_high)                     # :38,41
         o.gp_interp(self.real_high, self.fake_high, alpha, self.xhat, self.real_c, self.fake_c)   # :46 -> _gp(real_high, fake_high)
+        if self.stacked:
+            return self._critic_passes_stacked(apply_update)
         xr, xk = (self.real_c, self.fake_c) if self.compact2 else (self.real_high, self.fake_high)
         s0, s1, s2 = (0, 1, 2) if C.fc1_fused else (None, None, None)
         C.P.zero_grad(skip="classifier.0.weight" if C.fc1_fused else None)    # :49 (fc1_flush WRITES that gradient)

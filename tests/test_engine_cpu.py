@@ -129,3 +129,36 @@ def test_state_dict_roundtrip():
     sd = eng.C.state_dict()
     for k, v in pc.items():
         assert torch.equal(sd[k], torch.from_numpy(v)), k
+
+
+@pytest.mark.parametrize("fs", [False, True])
+def test_stacked_critic_passes_equal_separate_passes(fs):
+    """TrainEngine(stacked=True) (opt-in: the real, generated and interpolated batch through the critic as ONE batch of 3B,
+    wasserstein.py:37, 38, 97 / :52 / :100-106) gives the scalars and critic gradients of the three separate passes; it needs the 128-wide critic
+    (bit masks) and the compact 2-channel inputs, so this runs at F = 128 on a 4 x 4 -> 32 x 32 tile, batch 2."""
+    from downgan_amd.engine import TrainEngineFS
+    from downgan_amd.layout import nchw_to_nhwc_padded
+    res = {}
+    for stacked in (True, False):
+        ops = EmuOps("f32")
+        B, S, F_ = 2, 4, 128
+        eng = (TrainEngineFS if fs else TrainEngine)(ops, S, F_, 2, B, HyperParams(batch_size=B), num_res_blocks=1, stacked=stacked)
+        assert eng.stacked == stacked and eng.compact2
+        eng.G.load_state_dict(synthetic.generator_params(F_, 2, 2, 1))
+        eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
+        coarse, fine = synthetic.tiles(B, 2, S)
+        xc = nchw_to_nhwc_padded(torch.from_numpy(coarse), eng.G.cin_p, ops.tdtype)
+        xf = nchw_to_nhwc_padded(torch.from_numpy(fine), eng.G.np_p, ops.tdtype)
+        eng.critic_iteration(xc, xf, torch.from_numpy(synthetic.alpha(B, 0)), apply_update=False)
+        res[stacked] = (eng.read_scalars(), eng.C.grad_dict())
+        # a generator iteration afterwards runs the single-pass methods on the first B rows of the stacked buffers
+        eng.generator_iteration(xc, xf, apply_update=False)
+        res[stacked] += (eng.read_scalars(True), eng.G.grad_dict())
+    (s1, g1, t1, h1), (s0, g0, t0, h0) = res[True], res[False]
+    for k in ("c_real_mean", "c_fake_mean", "gp_ret", "critic_loss"):
+        assert abs(s1[k] - s0[k]) <= 1e-6 * max(1.0, abs(s0[k])), (k, s1[k], s0[k])
+    for k in g0:
+        assert float((g1[k] - g0[k]).norm()) <= 1e-5 * float(g0[k].norm()) + 1e-12, k
+    assert abs(t1["g_loss"] - t0["g_loss"]) <= 1e-6 * max(1.0, abs(t0["g_loss"]))
+    for k in h0:
+        assert float((h1[k] - h0[k]).norm()) <= 1e-5 * float(h0[k].norm()) + 1e-12, k

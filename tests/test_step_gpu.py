@@ -217,3 +217,35 @@ def test_hip_graph_replay_equals_eager():
             # repetitions on MI355X): every scalar but w_estimate agrees to <= 4e-7, the trajectories of two runs separate by
             # the order of the fp32 atomics alone, eager vs eager as much as eager vs replay
             assert rel(a[k], b[k]) < 5e-5 or abs(a[k] - b[k]) < 5e-6, (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_stacked_critic_passes_equal_separate_passes(dtype):
+    """TrainEngine(stacked=True) (opt-in, DESIGN 7: real | fake | x-hat through the critic as one batch of 3B) against the three
+    separate passes on the HIP kernels: two train steps with updates at F = 128 (bit masks, compact inputs), 8 -> 64 tiles."""
+    res = {}
+    for stacked in (True, False):
+        ops = HipOps(dtype)
+        B, S, F_, nrb = 2, 8, 128, 1
+        eng = TrainEngine(ops, S, F_, 2, B, HyperParams(batch_size=B), num_res_blocks=nrb, stacked=stacked)
+        assert eng.stacked == stacked and eng.compact2
+        eng.G.load_state_dict(synthetic.generator_params(F_, 2, 2, nrb))
+        eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
+        coarse, fine = synthetic.tiles(B, 2, S)
+        xc = ops.zeros(B, S, S, eng.G.cin_p); ops.nchw_to_nhwc(torch.from_numpy(coarse).cuda(), xc)
+        xf = ops.zeros(B, 8 * S, 8 * S, eng.G.np_p); ops.nchw_to_nhwc(torch.from_numpy(fine).cuda(), xf)
+        eng.critic_iteration(xc, xf, torch.from_numpy(synthetic.alpha(B, 0)).cuda(), apply_update=False)
+        grads = eng.C.grad_dict()
+        out = [eng.read_scalars()]
+        for step in range(2):
+            ran_g = eng.train_step(xc, xf, torch.from_numpy(synthetic.alpha(B, step)).cuda())
+            out.append(eng.read_scalars(ran_g))
+        res[stacked] = (grads, out)
+    (g1, o1), (g0, o0) = res[True], res[False]
+    gtol = 2e-5 if dtype == "f32" else 2e-2        # bf16: the longer grids change the order of the fp32 atomics only, but
+    for k in g0:                                   # near-cancelling entries of bf16 products move by ulps of the products
+        assert float((g1[k] - g0[k]).norm()) <= gtol * float(g0[k].norm()) + 1e-12, k
+    stol = 1e-5 if dtype == "f32" else 2e-2
+    for a, b in zip(o1, o0):
+        for k in ("c_real_mean", "c_fake_mean", "gp_ret", "critic_loss"):
+            assert rel(a[k], b[k]) < stol or abs(a[k] - b[k]) < 1e-5, (k, a[k], b[k])
