@@ -72,6 +72,7 @@ _PROTOS = {
     "dg_last_conv_kernels": [],
     "dg_colsum": [_i, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp],
     "dg_repack_conv_weights": [_i, _i, _vp, _vp, _i, _i, _vp],
+    "dg_repack_dense_dgrad": [_i, _vp, _i, _i, _vp, _vp],
     "dg_wgrad_unswap": [_vp, _vp, _i, _i, _vp],
     "dg_linear_fwd": [_i, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i64, _vp],
     "dg_linear_dx": [_i, _i, _vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _f, _i, _i, _i64, _vp],

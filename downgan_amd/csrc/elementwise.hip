@@ -557,6 +557,39 @@ extern "C" int dg_repack_conv_weights(int dtype, int kind, const float* master, 
   return dg_check_launch();
 }
 
+// Data-gradient packs of a dense block's "virtual" convs (engine.NativeGenerator: the adjoint of slab slice j is one conv over the
+// stacked adjoints of convs j+1..n).  masters[k-1] = conv k's fp32 weight [F][9][k*F]; dst = for j = 0..n-1 the kind-1 pack of
+// the virtual conv V_j (F inputs, (n-j)*F outputs): dst_j[ci][tap][(k-j-1)*F + co] = W_k[co][tap][j*F + ci], k = j+1..n,
+// the packs concatenated.  One launch per block instead of a gather + repack per slice.
+struct DensePackArgs { const float* w[8]; };
+template <typename T>
+__global__ void dense_dgrad_pack_kernel(const DensePackArgs a, T* dst, int F, int n) {
+  const long long per = 9ll * F * F;                   // elements per (slice, conv) pair
+  const long long total = per * n * (n + 1) / 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int j = 0;
+    long long base = 0;
+    while (i >= base + per * (n - j)) { base += per * (n - j); ++j; }
+    const long long r = i - base;                      // index inside dst_j = [F][9][(n - j) * F]
+    const int cov = (int)(r % ((long long)(n - j) * F));
+    const long long t = r / ((long long)(n - j) * F);
+    const int tap = (int)(t % 9), ci = (int)(t / 9);
+    const int k = j + 1 + cov / F, co = cov % F;       // conv k (1-based), its output channel co
+    st_elem(dst + i, a.w[k - 1][((long long)co * 9 + tap) * ((long long)k * F) + (long long)j * F + ci]);
+  }
+}
+extern "C" int dg_repack_dense_dgrad(int dtype, const float* const* masters, int nconv, int F, void* dst, void* stream) {
+  if (!masters || !dst || nconv < 1 || nconv > 8 || F <= 0 || F % 8) return DG_ERR_BAD_ARG;
+  DensePackArgs a{};
+  for (int k = 0; k < nconv; ++k) { if (!masters[k]) return DG_ERR_BAD_ARG; a.w[k] = masters[k]; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned nb = ew_blocks(9ll * F * F * nconv * (nconv + 1) / 2);
+  if (dtype == DG_F32) hipLaunchKernelGGL(dense_dgrad_pack_kernel<float>, dim3(nb), dim3(256), 0, st, a, (float*)dst, F, nconv);
+  else if (dtype == DG_BF16) hipLaunchKernelGGL(dense_dgrad_pack_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, a, (bf16_t*)dst, F, nconv);
+  else return DG_ERR_BAD_DTYPE;
+  return dg_check_launch();
+}
+
 extern "C" const char* dg_version(void) { return "downgan_hip 0.1.0 (gfx950)"; }
 
 // ------------------------------------------------------------------ resident-dataset minibatch gather (data feed)

@@ -563,7 +563,6 @@ class NativeGenerator:
         self.cv_v = [Conv(B, S, S, F_, (5 - j) * F_, net="G") for j in range(5)]
         self._vsize = [(5 - j) * F_ * 9 * F_ for j in range(5)]
         self._vpack = [o.zeros(sum(self._vsize)) for _ in range(self.ndrb)]
-        self._vtmp = o.zeros(5 * F_ * 9 * F_, dtype=torch.float32)
         P.after_refresh.append(self._rebuild_vpacks)
         if self.f8:
             P.after_refresh.append(self._requantise_weights)
@@ -624,15 +623,10 @@ class NativeGenerator:
 
     def _rebuild_vpacks(self):
         """after every optimizer step / load: rows (k-j-1)F.. of slice j's virtual weight = columns [jF, (j+1)F) of conv k."""
-        o, P, F_ = self.ops, self.P, self.F
+        o, P = self.ops, self.P
         for d in range(self.ndrb):
             pre = f"res_blocks.{d // 3}.dense_blocks.{d % 3}.b"
-            ws = [P.view(P.p, f"{pre}{k}.0.weight") for k in range(1, 6)]           # [F, 9, kF] fp32 masters
-            for j in range(5):
-                n = self._vsize[j]
-                tmp = self._vtmp[:n].view((5 - j) * F_, 9, F_)
-                torch.cat([ws[k - 1][:, :, j * F_:(j + 1) * F_] for k in range(j + 1, 6)], 0, out=tmp)
-                o.repack(self._vtmp[:n], self.vpack(d, j), (5 - j) * F_, F_, 1)
+            o.repack_dense([P.view(P.p, f"{pre}{k}.0.weight").reshape(-1) for k in range(1, 6)], self._vpack[d], self.F)
 
     # ---- forward -----------------------------------------------------------------------------------
     def _slab(self, d, save):

@@ -345,6 +345,16 @@ class HipOps:
         assert dst.dtype == self.tdtype and dst.numel() == cout * 9 * cin
         check(self.lib.dg_repack_conv_weights(self.dg, kind, _ptr(master), _ptr(dst), cout, cin, self._stream()), "dg_repack_conv_weights")
 
+    def repack_dense(self, masters, dst, F_):
+        """masters[k-1]: fp32 weight [F, 9, k*F] of conv k of a dense block -> dst: the stacked data-gradient packs of its slab
+        slices (dg_repack_dense_dgrad), concatenated."""
+        n = len(masters)
+        for k, m in enumerate(masters):
+            assert m.dtype == torch.float32 and m.is_contiguous() and m.numel() == F_ * 9 * (k + 1) * F_
+        assert dst.dtype == self.tdtype and dst.is_contiguous() and dst.numel() == 9 * F_ * F_ * n * (n + 1) // 2
+        pm = (C.c_void_p * n)(*[m.data_ptr() for m in masters])
+        check(self.lib.dg_repack_dense_dgrad(self.dg, pm, n, F_, _ptr(dst), self._stream()), "dg_repack_dense_dgrad")
+
     def wgrad_unswap(self, tmp, dw, cout, cin):
         """dw[co][t][ci] += tmp[ci][8 - t][co] (both fp32 flat): see dg_wgrad_unswap."""
         assert tmp.dtype == torch.float32 and dw.dtype == torch.float32 and tmp.numel() == dw.numel() == cout * 9 * cin

@@ -163,6 +163,11 @@ int dg_conv3x3_plan(const dg_conv_geom* g, int kind, dg_gg_desc* out);
  *   kind 0 (forward pack): same layout cast to `dtype`;  kind 1 (dgrad pack): dst[ci][tap][co]. */
 int dg_repack_conv_weights(int dtype, int kind, const float* master, void* dst, int CoutP, int CinP,
                            void* stream);
+/* Data-gradient packs of a dense block's stacked ("virtual") convs: masters[k-1] = conv k's fp32 weight [F][9][k*F], k = 1..nconv
+ * (generator.py:14-41).  dst = for j = 0..nconv-1 the kind-1 pack of the conv that takes the adjoints of convs j+1..nconv
+ * ((nconv-j)*F channels) to the adjoint of slab slice j (F channels): dst_j[ci][tap][(k-j-1)*F + co] = W_k[co][tap][j*F + ci];
+ * the packs concatenated, 9*F*F*nconv*(nconv+1)/2 elements of `dtype`. */
+int dg_repack_dense_dgrad(int dtype, const float* const* masters, int nconv, int F, void* dst, void* stream);
 /* Two helpers for layers with <= 2 real OUTPUT channels (generator conv3.2, generator.py:80), whose backward is HBM-bound:
  * dg_repack_conv_weights kind 2 = kind 1 with mirrored taps, the pack with which that layer's data gradient is a forward conv of
  * dy over its 2 real channels (im2col kernel); dg_wgrad_unswap: dw[co][t][ci] += tmp[ci][8-t][co], which folds a weight-gradient

@@ -248,6 +248,14 @@ class EmuOps:
         else:                                    # kind 2: data-gradient pack with mirrored taps
             dst.copy_(m.permute(2, 1, 0).flip(1).reshape(-1).to(dst.dtype))
 
+    def repack_dense(self, masters, dst, F_):
+        n, off = len(masters), 0
+        for j in range(n):
+            wv = torch.cat([masters[k - 1].view(F_, 9, k * F_)[:, :, j * F_:(j + 1) * F_] for k in range(j + 1, n + 1)], 0).contiguous()
+            size = wv.numel()
+            self.repack(wv.reshape(-1), dst[off:off + size], (n - j) * F_, F_, 1)
+            off += size
+
     def wgrad_unswap(self, tmp, dw, cout, cin):
         dw.view(cout, 9, cin).add_(tmp.view(cin, 9, cout).flip(1).permute(2, 1, 0))
 

@@ -165,6 +165,22 @@ def test_conv_wgrad_dense_block(N, H, W, n):
         assert (dbs[k].cpu() - dbs_ref[k]).abs().max().item() <= 8e-4 * float(dbs_ref[k].abs().max()), k
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("F,n", [(16, 5), (128, 5), (32, 3)])
+def test_repack_dense_dgrad(dtype, F, n):
+    """dg_repack_dense_dgrad: the stacked data-gradient packs of a dense block in one launch == gather + dg_repack_conv_weights
+    per slab slice (the emulation's definition), bit for bit."""
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(41)
+    masters = [torch.randn(F * 9 * (k + 1) * F, generator=g) for k in range(n)]
+    total = 9 * F * F * n * (n + 1) // 2
+    ref = torch.zeros(total, dtype=emu.tdtype)
+    emu.repack_dense(masters, ref, F)
+    dst = torch.zeros(total, dtype=emu.tdtype).cuda()
+    hip.repack_dense([m.cuda() for m in masters], dst, F)
+    assert torch.equal(dst.cpu(), ref)
+
+
 def test_conv_slab_views_f32():
     """channel-slice views of a wider slab as input and output (dense-block layout)."""
     hip, emu = pair("f32")
