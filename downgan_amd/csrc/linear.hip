@@ -6,6 +6,7 @@
 // is used by exactly one wave); dx and dw are VALU streaming kernels that read each weight /
 // activation 16-B chunk once per small register tile.
 #include "dg_internal.h"
+#include <stdlib.h>
 
 template <typename T> struct MmaL;
 template <> struct MmaL<bf16_t> {
@@ -19,6 +20,32 @@ template <> struct MmaL<float> {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+// ---- helpers of the packed-fp32 streaming kernels (lin_dx_wide_kernel, lin_dw_wide_kernel)
+typedef __attribute__((ext_vector_type(2))) float dg_f32x2_t;
+template <typename T> struct LdX4;
+// one row's 4 elements per lane through a buffer descriptor based at the (workgroup-uniform) row: scalar base + 32-bit lane
+// offset.  Written as pointer arithmetic the compiler hoists `x + k` into a 64-bit VGPR pair per lane and serialises the loads.
+typedef __attribute__((ext_vector_type(2))) unsigned int dg_u32x2_t;
+template <> struct LdX4<float> {
+  typedef dg_u32x4_t raw;
+  static __device__ __forceinline__ raw load(const float* row, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)row, 0, -1, 0x00020000), voff, 0, 0);
+  }
+  static __device__ __forceinline__ void cvt(const raw& t, dg_f32x2_t& a, dg_f32x2_t& b) {
+    a = dg_f32x2_t{__uint_as_float(t[0]), __uint_as_float(t[1])}; b = dg_f32x2_t{__uint_as_float(t[2]), __uint_as_float(t[3])};
+  }
+};
+template <> struct LdX4<bf16_t> {
+  typedef dg_u32x2_t raw;
+  static __device__ __forceinline__ raw load(const bf16_t* row, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(__builtin_amdgcn_make_buffer_rsrc((void*)row, 0, -1, 0x00020000), voff, 0, 0);
+  }
+  static __device__ __forceinline__ void cvt(const raw& t, dg_f32x2_t& a, dg_f32x2_t& b) {
+    a = dg_f32x2_t{__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u)};
+    b = dg_f32x2_t{__uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
   }
 };
 
@@ -189,6 +216,83 @@ __global__ __launch_bounds__(256) void lin_dx_kernel(const float* __restrict__ d
   }
 }
 
+// The same product with 32 batch rows per pass over W (the 16-row kernel above streams the 0.94 GB FC1 matrix twice for a batch
+// of 32) and half the VALU slots: a lane owns 4 consecutive k of all 32 rows = 64 float2 accumulators fed by v_pk_fma_f32; the
+// adjoint values sit TRANSPOSED in LDS ([o][32 rows]: eight broadcast ds_read_b128 per weight row against 64 packed FMAs, read
+// one weight row ahead), the weight rows arrive through a row-based buffer descriptor six rows ahead of their arithmetic.
+template <typename T, typename TO>
+__global__ __launch_bounds__(256, 2) void lin_dx_wide_kernel(const float* __restrict__ dy, int ldo, const T* __restrict__ w,
+                                                             long long ldw, TO* dx, long long lddx, const T* mask,
+                                                             long long ldmask, float slope, int B, int O, long long K) {
+  constexpr int BG = 32;
+  __shared__ __attribute__((aligned(16))) float sdyT[129 * BG];          // [o][b] (+ one zero row read past the end)
+  const int b0 = blockIdx.y * BG;
+  for (int i = threadIdx.x; i < (O + 1) * BG; i += 256) {
+    const int o = i / BG, b = i % BG;
+    sdyT[i] = (o < O && b0 + b < B) ? dy[(long long)(b0 + b) * ldo + o] : 0.f;
+  }
+  __syncthreads();
+  const long long k = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (k >= K) return;
+  const unsigned voff = (unsigned)k * (unsigned)sizeof(T);
+  dg_f32x2_t acc[BG][2];
+#pragma unroll
+  for (int b = 0; b < BG; ++b) acc[b][0] = acc[b][1] = dg_f32x2_t{0.f, 0.f};
+  // The 32 adjoint values of a weight row: eight broadcast ds_read_b128, issued one row AHEAD as inline asm (written as plain
+  // loads the compiler splits them into ds_read_b32 and sinks each in front of its FMA pair with a wait).
+  typedef __attribute__((ext_vector_type(4))) float f4_t;
+  f4_t d[2][BG / 4];
+  const unsigned lds0 = (unsigned)(unsigned long long)((__attribute__((address_space(3))) float*)sdyT);
+  auto read_row = [&](f4_t (&dst)[BG / 4], int o) {
+    const unsigned adr = lds0 + (unsigned)o * (BG * 4);
+#pragma unroll
+    for (int q = 0; q < BG / 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[q]) : "v"(adr), "n"(16 * q));
+  };
+  auto landed = [&](f4_t (&dst)[BG / 4]) {          // all but the eight reads issued after this row's (LDS returns in order)
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]), "+v"(dst[5]), "+v"(dst[6]), "+v"(dst[7]));
+  };
+  auto row_fma = [&](const typename LdX4<T>::raw& wr, const f4_t (&dv)[BG / 4]) {
+    dg_f32x2_t wa, wb;
+    LdX4<T>::cvt(wr, wa, wb);
+#pragma unroll
+    for (int q = 0; q < BG / 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const dg_f32x2_t d2 = {dv[q][e], dv[q][e]};
+        acc[4 * q + e][0] = __builtin_elementwise_fma(d2, wa, acc[4 * q + e][0]);
+        acc[4 * q + e][1] = __builtin_elementwise_fma(d2, wb, acc[4 * q + e][1]);
+      }
+  };
+  auto wrow = [&](int o) { return LdX4<T>::load(w + (long long)(o < O ? o : O - 1) * ldw, voff); };   // past the end: a harmless re-read
+  // weight rows PD ahead of their arithmetic (two waves per SIMD at ~210 VGPRs: the loads in flight are what hides HBM latency)
+  constexpr int PD = 6;
+  typename LdX4<T>::raw wq[PD];
+#pragma unroll
+  for (int u = 0; u < PD; ++u) wq[u] = wrow(u);
+  read_row(d[0], 0);
+  for (int o = 0; o < O; o += PD) {                  // rows past O: the zero adjoint row times a re-read of the last weight row
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      read_row(d[(u + 1) & 1], o + u + 1 < O ? o + u + 1 : O);
+      landed(d[u & 1]);
+      row_fma(wq[u], d[u & 1]);
+      wq[u] = wrow(o + u + PD);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < BG; ++b) {
+    if (b0 + b >= B) break;
+    float v[4] = {acc[b][0][0], acc[b][0][1], acc[b][1][0], acc[b][1][1]};
+    if (mask) {
+      float mv[4];
+      ld4(mask + (long long)(b0 + b) * ldmask + k, mv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= leaky_grad(mv[e], slope);
+    }
+    st4(dx + (long long)(b0 + b) * lddx + k, v);
+  }
+}
+
 extern "C" int dg_linear_dx(int dtype, int out_dtype, const float* dy, int ldo, const void* w, int64_t ldw, void* dx,
                             int64_t lddx, const void* mask, int64_t ldmask, float mask_slope, int B, int O, int64_t K,
                             void* stream) {
@@ -196,6 +300,20 @@ extern "C" int dg_linear_dx(int dtype, int out_dtype, const float* dy, int ldo, 
   if (B <= 0 || O <= 0 || O > 128 || K <= 0 || K % 8 || ldw % 8 || lddx % 8) return DG_ERR_BAD_SHAPE;
   if (mask && ldmask % 8) return DG_ERR_BAD_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const bool no_wide = getenv("DG_LIN_NODXWIDE") != nullptr;
+  if (!no_wide && K >= 4096 && (long long)K * 4 < (1ll << 32) && B >= 16) {        // the FC1-sized products: 32 rows per pass, packed FMAs
+    dim3 gridw((unsigned)((K / 4 + 255) / 256), (unsigned)((B + 31) / 32));
+    if (dtype == DG_F32 && out_dtype == DG_F32) {
+      hipLaunchKernelGGL((lin_dx_wide_kernel<float, float>), gridw, dim3(256), 0, st, dy, ldo, (const float*)w, (long long)ldw, (float*)dx,
+                         (long long)lddx, (const float*)mask, (long long)ldmask, mask_slope, B, O, (long long)K);
+      return dg_check_launch();
+    }
+    if (dtype == DG_BF16 && out_dtype == DG_BF16) {
+      hipLaunchKernelGGL((lin_dx_wide_kernel<bf16_t, bf16_t>), gridw, dim3(256), 0, st, dy, ldo, (const bf16_t*)w, (long long)ldw, (bf16_t*)dx,
+                         (long long)lddx, (const bf16_t*)mask, (long long)ldmask, mask_slope, B, O, (long long)K);
+      return dg_check_launch();
+    }
+  }
   constexpr int BG = 16;             // batch rows per pass over W: a batch of 32 streams the matrix twice (was 4x with 8)
   const int epc = dtype == DG_F32 ? 4 : 8;
   dim3 grid((unsigned)((K / epc + 255) / 256), (unsigned)((B + BG - 1) / BG));
@@ -283,31 +401,6 @@ extern "C" int dg_linear_dw(int dtype, const float* dy, int ldo, const void* x, 
 // by SCALAR loads (SGPR operands of the packed FMAs: no LDS, no barrier); x is loaded once per wave through a buffer descriptor
 // based at the row (the waves of a workgroup hit L1/L2 for the same 1-KB runs), one register set ahead of its arithmetic.
 // `accumulate == 0` writes the result: neither the gradient zero-fill nor the read of dw is needed.
-typedef __attribute__((ext_vector_type(2))) float dg_f32x2_t;
-template <typename T> struct LdX4;
-// one row's 4 elements per lane through a buffer descriptor based at the (workgroup-uniform) row: scalar base + 32-bit lane
-// offset.  Written as pointer arithmetic the compiler hoists `x + k` into a 64-bit VGPR pair per lane and serialises the loads.
-typedef __attribute__((ext_vector_type(2))) unsigned int dg_u32x2_t;
-template <> struct LdX4<float> {
-  typedef dg_u32x4_t raw;
-  static __device__ __forceinline__ raw load(const float* row, unsigned voff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)row, 0, -1, 0x00020000), voff, 0, 0);
-  }
-  static __device__ __forceinline__ void cvt(const raw& t, dg_f32x2_t& a, dg_f32x2_t& b) {
-    a = dg_f32x2_t{__uint_as_float(t[0]), __uint_as_float(t[1])}; b = dg_f32x2_t{__uint_as_float(t[2]), __uint_as_float(t[3])};
-  }
-};
-template <> struct LdX4<bf16_t> {
-  typedef dg_u32x2_t raw;
-  static __device__ __forceinline__ raw load(const bf16_t* row, unsigned voff) {
-    return __builtin_amdgcn_raw_buffer_load_b64(__builtin_amdgcn_make_buffer_rsrc((void*)row, 0, -1, 0x00020000), voff, 0, 0);
-  }
-  static __device__ __forceinline__ void cvt(const raw& t, dg_f32x2_t& a, dg_f32x2_t& b) {
-    a = dg_f32x2_t{__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u)};
-    b = dg_f32x2_t{__uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
-  }
-};
-
 template <typename T, bool ACC, int NWV>
 __global__ __launch_bounds__(64 * NWV, 2) void lin_dw_wide_kernel(const float* __restrict__ dy, int ldo, const T* __restrict__ x,
                                                                   long long ldx, float* dw, long long lddw, int B, int O,
