@@ -2024,9 +2024,7 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
   const int ob_src = (l15 + 32 * (g & 1)) * 4, ob_sh = 16 * (g >> 1);
   const unsigned ob_off = (unsigned)((l15 * ldb + (c0 >> 6) * 4 + 2 * g) * 2);
   const float zero16[16] = {};
-  // tiled order: a wave walks four vertically adjacent groups, so rows r, r+1 of the next group are rows r+1, r+2 of the current
-  // one: only the NEW bottom row is fetched (lanes 36-53) and the assembled register slides up 18 lanes (one more ds_bpermute)
-  auto gather = [&](int grp, bool bottom_only) -> unsigned {
+  auto gather = [&](int grp) -> unsigned {
     const bool live = grp >= 0;
     const unsigned m0 = live ? (unsigned)grp * 16u : 0u;
     const unsigned tq = m0 / (unsigned)a.Wg;
@@ -2036,12 +2034,9 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) + pbase * a.ldx * ES), 0,
                                                                       (int)DG_OOB_OFF, 0x00020000);
     const int mrel = (int)((long long)m0 - pbase) + ld_r * a.Ws + ld_c;
-    const bool ok = (int)live & (int)(lane < 54) & (int)(lane >= (bottom_only ? 36 : 0)) & (int)((unsigned)sy < (unsigned)a.Hs) &
-                    (int)((unsigned)sx < (unsigned)a.Ws);
+    const bool ok = (int)live & (int)(lane < 54) & (int)((unsigned)sy < (unsigned)a.Hs) & (int)((unsigned)sx < (unsigned)a.Ws);
     return __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (unsigned)(mrel * (int)a.ldx * ES) : DG_OOB_OFF, 0, 0);
   };
-  auto slides = [&](int it) { return tiled && (it & 3) != 0; };      // group `it` of this wave continues the previous one downwards
-  const int slide_src = (lane + 18) * 4;
   // group order.  tiled (image height a multiple of 16): a workgroup walks 16x16-pixel tiles, wave w rows 4w..4w+3 of each (the
   // write pattern of the tiled conv kernels: 3.6 against 3.3 TB/s for the linear order, whose 4096 waves write one 16-MB window);
   // otherwise wave k of the grid takes groups k, k + waves, ...
@@ -2057,15 +2052,10 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
   };
   // a group's pixels are fetched two groups ahead (memory operations retire in order: a load comes back only after the stores
   // issued before it have been acknowledged)
-  unsigned x0 = gather(grp_of(0), false), x1 = gather(grp_of(1), slides(1)), xa = 0u;
+  unsigned x0 = gather(grp_of(0)), x1 = gather(grp_of(1));
   for (int it = 0;; ++it) {
     const int grp = grp_of(it);
     if (grp < 0) break;
-    if (slides(it)) {                                  // rows r+1, r+2 of the previous group + the freshly loaded bottom row
-      const unsigned up = (unsigned)__builtin_amdgcn_ds_bpermute(slide_src, (int)xa);
-      x0 |= lane < 36 ? up : 0u;
-    }
-    xa = x0;
     const uint4 fb = make_uint4((unsigned)__builtin_amdgcn_ds_bpermute(perm_src[0], (int)x0),
                                 (unsigned)__builtin_amdgcn_ds_bpermute(perm_src[1], (int)x0) | ones,
                                 (unsigned)__builtin_amdgcn_ds_bpermute(perm_src[2], (int)x0),
@@ -2085,7 +2075,7 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
       mb[0] = __builtin_amdgcn_raw_buffer_load_b16(R.rbi, boff[0], 0, 0);
       mb[1] = __builtin_amdgcn_raw_buffer_load_b16(R.rbi, boff[1], 0, 0);
     }
-    const unsigned x2 = gather(grp_of(it + 2), slides(it + 2));
+    const unsigned x2 = gather(grp_of(it + 2));
     unsigned ob[2] = {0u, 0u};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
