@@ -81,4 +81,7 @@ class Dist:
 
     def barrier(self):
         if self.world_size > 1:
-            td.barrier()
+            if self.backend == "nccl":       # name the rank's own device: never let the barrier guess one
+                td.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                td.barrier()
