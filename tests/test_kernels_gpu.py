@@ -232,6 +232,24 @@ def test_linear(dtype, B, K, O):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,K,O", [(40, 4352, 100), (16, 4096, 112), (96, 8192, 7)])
+def test_linear_dx_wide_kernel_shapes(dtype, B, K, O):
+    """the 32-rows-per-pass input-gradient kernel (K >= 4096, B >= 16): a ragged last row group, an odd number of weight rows,
+    K not a multiple of the 1024-column workgroup span, with and without the LeakyReLU' mask."""
+    hip, emu = pair(dtype)
+    g = torch.Generator().manual_seed(9)
+    w = rnd((O, K), emu.tdtype, g, 0.1)
+    dy = torch.zeros(B, 128); dy[:, :O] = torch.randn(B, O, generator=g)
+    mask = rnd((B, K), emu.tdtype, g)
+    for m in (None, mask):
+        ref = torch.zeros(B, K, dtype=emu.tdtype)
+        emu.linear_dx(dy[:, :O], w, ref, mask=m, mask_slope=0.2)
+        dx = torch.full((B, K), 3.0, dtype=emu.tdtype).cuda()
+        hip.linear_dx(dy.cuda()[:, :O], w.cuda(), dx, mask=None if m is None else m.cuda(), mask_slope=0.2)
+        close(dx, ref, dtype, f"linear_dx wide B={B} K={K} O={O} mask={m is not None}")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_linear_dw_wide_three_passes(dtype):
     """96 concatenated rows (three passes of batch 32) x 100 real outputs in a 112-row gradient, K with a ragged last
     256-chunk: equals three accumulating dg_linear_dw calls (what the engine did per pass)."""
