@@ -437,7 +437,9 @@ def test_compact_two_channel_fields(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("N,H,W,co,cin_real", [(2, 32, 32, 128, 2), (1, 20, 12, 64, 2), (3, 16, 16, 16, 1), (1, 40, 24, 256, 2)])
+@pytest.mark.parametrize("N,H,W,co,cin_real", [(2, 32, 32, 128, 2), (1, 20, 12, 64, 2), (3, 16, 16, 16, 1), (1, 40, 24, 256, 2),
+                                               (1, 24, 32, 128, 2),      # barrier-free kernel, linear group order (height not a multiple of 16)
+                                               (2, 48, 64, 256, 1)])     # ... tiled order, two channel tiles, one real input channel
 def test_conv_fwd_small_cin(dtype, N, H, W, co, cin_real):
     """stride-1 forward with <= 2 real input channels: im2col kernel (bias+act, mask, residual epilogues)."""
     hip, emu = pair(dtype)
