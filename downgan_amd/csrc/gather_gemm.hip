@@ -1373,6 +1373,230 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
   return dg_check_launch();
 }
 
+#ifdef DG_LC_EXPERIMENT
+// EXPERIMENT (-DDG_LC_EXPERIMENT, DG_GG_LC=1): the four-wave halo kernel's tile with EIGHT waves in one workgroup per CU --
+// waves 0-3 COMPUTE (fragment reads, MFMAs, epilogue), waves 4-7 LOAD (weight DMA, patch loads / LDS stores): can one compute
+// wave per SIMD, freed of every vector-memory instruction in the loop, feed the matrix pipe as well as two waves that do both?
+__global__ __launch_bounds__(512, 1) void gg_halo_lc_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+  typedef bf16_t T;
+  constexpr bool S2 = false, PS = false;
+  constexpr int NW = 4;
+  constexpr int NT = 256, RPP = NT / 8;                                  // LOADER threads; patch rows staged per pass                              // threads; patch rows staged per pass
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
+  constexpr int BC = 32 * NW, KC = 8;                                    // 8 chunks per row: 64 bf16 / 32 fp32 channels
+  constexpr int PITCH = KC * 16 + 16;                                    // 144 B patch rows
+  constexpr int WROW = KC * 16;                                          // 128 B weight rows, chunk c of row r at c ^ ((r >> 1) & 7)
+  constexpr int NPL = (PROWS * KC + NT - 1) / NT;                        // 11 (6) patch chunks per thread
+  constexpr int NWL = BC * KC / NT;                                      // 4 weight pieces per wave and step
+  extern __shared__ __attribute__((aligned(16))) char dsm4w[];
+  char* const s_patch = dsm4w;                    // [PROWS][PITCH]
+  char* const s_w = dsm4w + PROWS * PITCH;        // [2][BC][WROW]
+
+  const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool compute = wave8 < 4;
+  const int wave = wave8 & 3, tid = threadIdx.x & 255;      // index inside the role's four waves
+  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tile_c = tile % a.nct;
+  unsigned rest = tile / a.nct;
+  const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
+  const int ty0 = (rest % tiles_y) * TH;
+  const int img = rest / tiles_y;
+  const int c0 = tile_c * BC;
+  const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0, RPP)
+  const int wq = wave & 3, wh = wave >> 2;        // tile rows 4*wq.., channel half wh (0 unless NW = 8)
+  const int sy_base = S2 ? (ty0 > 0 ? 2 * (ty0 - 1) : 0) : (ty0 - 1 > 0 ? ty0 - 1 : 0);
+  const char* Xb = PS ? reinterpret_cast<const char*>(a.x) + ((long long)img * 2 * a.Hs + 2 * sy_base) * (2 * a.Ws) * a.ldx * ES
+                      : reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
+  const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ncbr = a.cch / KC;                    // real channel blocks
+  const int ncb = S2 ? 4 * ncbr : ncbr;           // (plane, channel block) pairs, plane-major
+  const int nsteps = ncbr * a.ntaps;
+  auto plane_of = [&](int vcb) { return S2 ? (int)(vcb >= ncbr) + (int)(vcb >= 2 * ncbr) + (int)(vcb >= 3 * ncbr) : 0; };
+  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : a.ntaps; };
+
+  unsigned woff[NWL];                             // DMA piece i of this wave: rows wave*32 + 8i .. +7, lane = (row, physical chunk)
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    int row = wave * 32 + i * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    row = perm64(row);                              // LDS row holds output channel c0 + perm64(row)
+    if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;
+    woff[i] = (unsigned)((long long)row * a.ldw * ES) + logical * 16;
+  }
+  auto tap_code = [&](int vcb, int tap) {
+    const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap;
+    return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
+  };
+  u32x4_t rp[NPL];
+  auto load_patch = [&](int vcb) {
+    const int plane = plane_of(vcb), cb = vcb - plane * ncbr;
+    const int ppy = plane >> 1, ppx = plane & 1;
+    const int psq = PS ? (cb * KC) / a.cps_src_chunks : 0;                 // channel quarter of this block
+    const int psy = psq >> 1, psx = psq & 1;
+    const long long cboff = PS ? (long long)(cb * KC - psq * a.cps_src_chunks) * EPC * ES : (long long)cb * KC * EPC * ES;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + cboff), 0, (int)DG_OOB_OFF, 0x00020000);
+    int r0v = r0;
+    asm volatile("" : "+v"(r0v));
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0v + RPP * i;
+      const int py = pr / PW, px = pr - py * PW;
+      const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
+      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+      const unsigned off = !ok ? DG_OOB_OFF
+                           : PS ? (unsigned)(((2 * (sy - sy_base) + psy) * (2 * a.Ws) + 2 * sx + psx) * a.ldx * ES) + cc * 16
+                                : (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16;
+      rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  char* const st_base = s_patch + r0 * PITCH + cc * 16;
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0 + RPP * i;
+      if (pr < PROWS) *reinterpret_cast<uint4*>(st_base + i * RPP * PITCH) = __builtin_bit_cast(uint4, rp[i]);
+    }
+  };
+  typedef int i32x4h_t __attribute__((ext_vector_type(4)));
+  i32x4h_t w_rs;
+  int w_dst0 = 0;
+  auto dma_setup = [&](int vcb, int tap, int slot) {
+    const unsigned code = tap_code(vcb, tap);
+    const long long wo = (long long)(code >> 4) * a.Cred + (vcb - plane_of(vcb) * ncbr) * KC * EPC;
+    const unsigned long long wbase = (unsigned long long)(Wb + wo * ES);
+    w_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wbase);
+    w_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(wbase >> 32) & 0xffff);
+    w_rs[2] = (int)DG_OOB_OFF;
+    w_rs[3] = 0x00020000;
+    w_dst0 = __builtin_amdgcn_readfirstlane(
+        (int)(unsigned long long)((__attribute__((address_space(3))) char*)(s_w + slot * (BC * WROW) + (wave * 32) * WROW)));
+  };
+  auto dma_piece = [&](int i) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(w_dst0 + i * 8 * WROW), "v"(woff[i]), "s"(w_rs) : "memory");
+  };
+  auto dma_w = [&](int cb, int tap, int slot) {
+    dma_setup(cb, tap, slot);
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) dma_piece(i);
+  };
+  auto barrier_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
+  auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPL) : "memory"); __syncthreads(); };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const char* fa_k[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) fa_k[kk] = s_w + (wh * 128 + l15) * WROW + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) * 16);
+  const char* const fb_lane = s_patch + l15 * PITCH + g * 16;
+  auto read_frags = [&](uint4 (&fa)[8], uint4 (&fb)[4], int pa, const char* pb, int kk) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] = *reinterpret_cast<const uint4*>(fa_k[kk] + pa + j * 16 * WROW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + kk * 64);
+  };
+  auto mma_rows = [&](const uint4 (&fa)[8], const uint4 (&fb)[4], int j0) {     // two weight fragments x four pixel rows
+#pragma unroll
+    for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
+  };
+  auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps_of(c_)) { t_ = 0; ++c_; } };
+  auto patch_ptr = [&](int vcb_, int tap_) -> const char* {
+    const unsigned code = tap_code(vcb_, tap_);
+    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
+    return fb_lane + ((wq * 4 + 1 + dy) * PW + 1 + dx) * PITCH;
+  };
+
+  int cb = 0, tap = 0, cbw = 0, tapw = 0;
+  adv(cbw, tapw); adv(cbw, tapw);      // -> W[2]
+  auto next_of = [&](int& ntap, int& ncbn, int ntaps_cb) { ntap = tap + 1; ncbn = cb; if (ntap == ntaps_cb) { ntap = 0; ncbn = cb + 1; } };
+  if (!compute) {
+    // ---------------- loader waves: every vector-memory instruction of the tile loop
+    load_patch(0);
+    dma_w(0, 0, 0);
+    if (nsteps > 1) { int c1 = 0, t1 = 0; adv(c1, t1); dma_w(c1, t1, 1); }
+    store_patch();
+    barrier_all();
+    for (int s = 0; s < nsteps; ++s) {
+      const bool more = s + 1 < nsteps;
+      int ntap, ncbn;
+      const int ntaps_cb = ntaps_of(cb);
+      next_of(ntap, ncbn, ntaps_cb);
+      const bool swap = ntap == 0 && more;
+      const bool patch_now = cb + 1 < ncb && (ntaps_cb == 1 || tap == 0);
+      const bool fetch = s + 2 < nsteps;
+      if (patch_now) load_patch(cb + 1);
+      if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
+      if (swap) { store_patch(); barrier_all(); }
+      if (fetch) { dma_setup(cbw, tapw, s & 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma_piece(q);
+      }
+      adv(cbw, tapw);
+      tap = ntap; cb = ncbn;
+    }
+    return;
+  }
+  // ---------------- compute waves: fragment reads, MFMAs, epilogue; no vector-memory instruction until the epilogue
+  __syncthreads();
+  uint4 fa[8], fb[4];
+  const char* pb = patch_ptr(0, 0);
+  int pa = 0;
+  read_frags(fa, fb, pa, pb, 0);
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    int ntap, ncbn;
+    const int ntaps_cb = ntaps_of(cb);
+    next_of(ntap, ncbn, ntaps_cb);
+    const bool swap = ntap == 0 && more;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mma_rows(fa, fb, 2 * q);
+      asm volatile("" : "+v"(acc[2 * q][0]), "+v"(acc[2 * q][1]), "+v"(acc[2 * q][2]), "+v"(acc[2 * q][3]),
+                        "+v"(acc[2 * q + 1][0]), "+v"(acc[2 * q + 1][1]), "+v"(acc[2 * q + 1][2]), "+v"(acc[2 * q + 1][3]) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      fa[2 * q] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q) * 16 * WROW);
+      fa[2 * q + 1] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q + 1) * 16 * WROW);
+      asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + 64);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mma_rows(fa, fb, 2 * q);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    pa = ((s + 1) & 1) * (BC * WROW);
+    pb = patch_ptr(ncbn < ncb ? ncbn : 0, ntap);
+    if (swap) __syncthreads();
+    if (more) read_frags(fa, fb, pa, pb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    tap = ntap; cb = ncbn;
+  }
+  halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
+}
+
+static int gg_launch_halo_lc(GGArgs& a, int N, hipStream_t st) {
+  constexpr int LDS_BYTES = 324 * 144 + 2 * 128 * 128;
+  DG_SET_MAX_LDS_ONCE((&gg_halo_lc_kernel), LDS_BYTES);
+  const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
+  a.nct = (unsigned)((a.Nout + 127) / 128);
+  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  g_last_kinds |= 8;
+  hipLaunchKernelGGL(gg_halo_lc_kernel, dim3(a.nwg), dim3(512), LDS_BYTES, st, a, tiles_x, tiles_y);
+  return dg_check_launch();
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // MXFP8 version of the four-wave halo kernel (BASELINE configs[4]: the critic's wide layers, critic.py:25-88): operands are
 // OCP E4M3 bytes with one E8M0 scale per block of 32 consecutive channels (csrc/quant.hip, which also records how the
@@ -2202,6 +2426,12 @@ static int gg_launch(GGArgs& a, int N, hipStream_t st) {
   {
     // default: the four-wave kernel, two workgroups per CU (measured +8-22 % over the eight-wave kernel on every layer);
     // it also takes single-tap launches (the 1-tap parity class of a stride-2 data gradient)
+#ifdef DG_LC_EXPERIMENT
+    if constexpr (sizeof(T) == 2) {
+      static const bool lc = getenv("DG_GG_LC") != nullptr;
+      if (lc && !no4w && a.cch % 8 == 0) return gg_launch_halo_lc(a, N, st);
+    }
+#endif
     if (!no4w && a.cch % 8 == 0) return gg_launch_halo4w<T, false>(a, N, st);
     // one reduction block and 2..8 full output-channel tiles: all channel tiles of a pixel tile in one workgroup
     static const bool no_ct = getenv("DG_GG_NOCT") != nullptr;
