@@ -1548,37 +1548,32 @@ __global__ __launch_bounds__(512, 1) void gg_halo_lc_kernel(const GGArgs a, int 
   }
   // ---------------- compute waves: fragment reads, MFMAs, epilogue; no vector-memory instruction until the epilogue
   __syncthreads();
-  uint4 fa[8], fb[4];
+  // TWO fragment sets: k-block 1 of a step is read while k-block 0 feeds the MFMAs, k-block 0 of the next step (behind the
+  // barrier that publishes its weight slot) while k-block 1 does -- one wave per SIMD has nobody else to cover its LDS latency
+  uint4 fa0[8], fb0[4], fa1[8], fb1[4];
   const char* pb = patch_ptr(0, 0);
   int pa = 0;
-  read_frags(fa, fb, pa, pb, 0);
+  read_frags(fa0, fb0, pa, pb, 0);
   for (int s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
     int ntap, ncbn;
     const int ntaps_cb = ntaps_of(cb);
     next_of(ntap, ncbn, ntaps_cb);
     const bool swap = ntap == 0 && more;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      mma_rows(fa, fb, 2 * q);
-      asm volatile("" : "+v"(acc[2 * q][0]), "+v"(acc[2 * q][1]), "+v"(acc[2 * q][2]), "+v"(acc[2 * q][3]),
-                        "+v"(acc[2 * q + 1][0]), "+v"(acc[2 * q + 1][1]), "+v"(acc[2 * q + 1][2]), "+v"(acc[2 * q + 1][3]) :: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      fa[2 * q] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q) * 16 * WROW);
-      fa[2 * q + 1] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q + 1) * 16 * WROW);
-      asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + 64);
+    read_frags(fa1, fb1, pa, pb, 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) mma_rows(fa, fb, 2 * q);
+    for (int q = 0; q < 4; ++q) mma_rows(fa0, fb0, 2 * q);
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     pa = ((s + 1) & 1) * (BC * WROW);
     pb = patch_ptr(ncbn < ncb ? ncbn : 0, ntap);
     if (swap) __syncthreads();
-    if (more) read_frags(fa, fb, pa, pb, 0);
+    if (more) read_frags(fa0, fb0, pa, pb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mma_rows(fa1, fb1, 2 * q);
     __builtin_amdgcn_sched_barrier(0);
     tap = ntap; cb = ncbn;
   }
