@@ -155,6 +155,33 @@ def test_forward_drop_in_modules():
     assert torch.allclose(G.generate(series, chunk_size=2), whole, atol=1e-6)
 
 
+def test_first_adam_move_has_the_float64_oracles_sign():
+    """Post-Adam parameters ENTRY BY ENTRY (stage.py:63-64): after one train step the share of entries of every critic and generator
+    parameter whose move has the float64 oracle's sign, weighted by |g|, is >= 0.999 (Adam's first step is -lr * sign(g); entries
+    whose gradient is fp32 rounding noise carry no weight).  Norm checks alone would pass a wrong update of a small slice."""
+    B, S, F_, cin, nrb = 2, 16, 16, 2, 2
+    eng, pg, pc, tc, tf, xc, xf = make(B, S, F_, cin, nrb, "f32")
+    d = torch.float64
+    o64 = ref_step.OracleTrainer({k: torch.from_numpy(v).to(d) for k, v in pg.items()}, {k: torch.from_numpy(v).to(d) for k, v in pc.items()},
+                                 ref_step.HP(batch_size=B), num_res_blocks=nrb)
+    alpha = torch.from_numpy(synthetic.alpha(B, 0))
+    _, cg = o64.critic_iteration(tc.to(d), tf.to(d), alpha.to(d))
+    _, gg = o64.generator_iteration(tc.to(d), tf.to(d))
+    assert eng.train_step(xc, xf, alpha.cuda())
+    for before, after, ref_after, grads in ((pc, eng.C.state_dict(), o64.PC, cg), (pg, eng.G.state_dict(), o64.PG, gg)):
+        for k, g in grads.items():
+            p0 = torch.from_numpy(before[k]).double()
+            da, db = torch.sign(after[k].double() - p0), torch.sign(ref_after[k].detach() - p0)
+            w = g.abs()
+            if float(w.sum()) == 0.0:
+                assert float(da.abs().sum()) == 0.0, k          # no gradient, no move
+                continue
+            share = float(((da == db).double() * w).sum() / w.sum())
+            assert share >= 0.999, (k, share)
+            moved = float((da != 0).double().mean())
+            assert moved > 0.99 or float((db != 0).double().mean()) <= moved + 1e-3, (k, moved)
+
+
 # (full-tile parity at BASELINE configs[1] shapes -- scalars, every gradient, bf16 vs the oracle -- lives in test_cfg2_parity_gpu.py)
 
 
@@ -177,7 +204,7 @@ def test_bf16_drift_at_full_tile_vs_fp32_native():
         for k in ("critic_loss", "gp_ret", "c_real_mean", "c_fake_mean"):
             a, b = res["bf16"][step][k], res["f32"][step][k]
             drift[f"{step}:{k}"] = abs(a - b) / max(abs(b), 1e-3)
-    for d in ("profiles", "gpurun_out"):
+    for d in ("gpurun_out",):        # scratch; copied into profiles/ by hand (a test run never rewrites tracked evidence)
         try:
             os.makedirs(os.path.join(os.path.dirname(GOLD), "..", d), exist_ok=True)
             with open(os.path.join(os.path.dirname(GOLD), "..", d, "bf16_vs_f32_native_cfg2_b2.json"), "w") as f:
