@@ -142,10 +142,16 @@ def pmc_traffic(kernel, args):
         d = json.load(f)
     if d.get("lib_sha256") != lib_sha256():
         return None, f"profiles/{os.path.basename(path)} is from another build of libdowngan_hip.so (stale): traffic withheld"
-    for k, v in d["kernels"].items():
-        if k.startswith(kernel):
-            return round(v["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(path)} (" + d["formula"] + ")"
-    return None, None
+    # every instantiation of the kernel (stride 1, stride 2 with 4 / 8 waves, pixel-shuffled source), weighted by its launches:
+    # the same set of launches `alg_bytes_per_launch` and `frac` are averaged over
+    inst = {k: v for k, v in d["kernels"].items() if k.startswith(kernel + "<")}
+    n = sum(v["launches"] for v in inst.values())
+    if not n:
+        return None, None
+    traffic = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in inst.values()) / n
+    src = (f"profiles/{os.path.basename(path)} (" + d["formula"] + f"; launch-weighted mean over the {len(inst)} instantiations "
+           + ", ".join(f"{k[len(kernel):]} x{v['launches']}" for k, v in inst.items()) + ")")
+    return round(traffic), src
 
 
 def self_launch(n):
@@ -161,6 +167,115 @@ def self_launch(n):
     return subprocess.run(cmd).returncode
 
 
+def build_engine(args, dtype, world, dist, local, rank, nsteps):
+    """Engine + HBM-resident synthetic inputs for `dtype` in {"bf16", "f32", "fp8", "fp8c"}."""
+    import torch
+    from downgan_amd import synthetic
+    from downgan_amd.engine import HyperParams, TrainEngine
+    from downgan_amd.ops import HipOps
+    B, S, F_, cin, nrb = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    is_f8 = dtype in ("fp8", "fp8c")
+    ops = HipOps("bf16" if is_f8 else dtype, f"cuda:{local}", f8_critic=is_f8, f8_generator=dtype == "fp8")
+    eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B * world), num_res_blocks=nrb, dist=dist, check_finite=args.check_finite)
+    eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))       # seed 0 on every rank
+    eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
+    coarse, fine = synthetic.tiles(B, cin, S, rank=rank)                      # seed 1234 + rank
+    xc = ops.zeros(B, S, S, eng.G.cin_p); ops.nchw_to_nhwc(torch.from_numpy(coarse).cuda(), xc)
+    xf = ops.zeros(B, 8 * S, 8 * S, eng.G.np_p); ops.nchw_to_nhwc(torch.from_numpy(fine).cuda(), xf)
+    del coarse, fine
+    alphas = [torch.from_numpy(synthetic.alpha(B, s, rank=rank)).cuda() for s in range(nsteps)]
+    return ops, eng, xc, xf, alphas
+
+
+def timed_steps(eng, ops, xc, xf, alphas, first, steps, dist, rehearse, kernel_timing, per_layer):
+    """Time exactly `steps` train steps (alphas[first:first+steps]) between barrier + device sync on both sides; MAX over ranks.
+    The step counter is aligned so that the region OPENS with a generator step: K timed steps then contain ceil(K / critic_iterations)
+    generator iterations for every --steps / --warmup combination -- never fewer than the long-run share."""
+    import torch
+
+    def complete_updates():
+        # the Adam updates are deferred behind the next forward (engine.py); finish them so that exactly the work of the steps
+        # issued so far lies before the synchronisation point
+        eng.C.P.sync(); eng.G.P.sync()
+    ci = eng.hp.critic_iterations
+    eng.num_steps = -(-eng.num_steps // ci) * ci
+    complete_updates()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if kernel_timing:
+        ops.prof = []
+        ops.per_layer = per_layer
+    t0 = time.perf_counter()
+    for s in range(first, first + steps):
+        eng.train_step(xc, xf, alphas[s])
+    complete_updates()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = t if rehearse else t.cuda()
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof, ops.prof = ops.prof, None
+    return elapsed, prof
+
+
+def summarise_kernels(prof, elapsed, steps, peak, args, per_layer, with_traffic=True):
+    """Live HIP-event timings of the launches in the timed region -> (roofline of the dominant kernel, critic stack, kernels table)."""
+    if not prof:
+        return None, None, {}
+    agg, kernels = {}, {}
+    for tag, flops, nbytes, s_ev, e_ev in prof:
+        a = agg.setdefault(tag, [0.0, 0.0, 0, 0.0])
+        a[0] += flops; a[1] += s_ev.elapsed_time(e_ev) * 1e-3; a[2] += 1; a[3] += nbytes
+    for tag, (fl, sec, n, nb_) in agg.items():
+        kernels[tag] = {"launches": n, "seconds": round(sec, 4), "tflops": round(fl / sec / 1e12, 2) if sec > 0 else None}
+        if per_layer:
+            kernels[tag]["alg_tbps"] = round(nb_ / sec / 1e12, 2) if sec > 0 else None
+    # dominant kernel: gg_halo4w_kernel (conv forward of both strides + data gradients; all its instantiations).  Only calls that were
+    # served by that kernel alone (tag suffix k8) are counted, so achieved = algorithmic flops of those
+    # launches / their summed launch durations, and launches/seconds give the average launch duration.
+    halo = [t for t in agg if t.endswith(":k8")]
+    fl = sum(agg[t][0] for t in halo)
+    sec = sum(agg[t][1] for t in halo)
+    nl = sum(agg[t][2] for t in halo)
+    ach = fl / sec / 1e12 if sec > 0 else 0.0
+    alg_bytes = sum(agg[t][3] for t in halo) / max(nl, 1)
+    traffic, traffic_src = pmc_traffic("gg_halo4w_kernel", args) if with_traffic else (None, None)
+    roofline = {"kernel": "gg_halo4w_kernel (implicit-GEMM conv3x3: forward, stride 1 and 2, and data gradients)", "bound": "mfma",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "alg_bytes_per_launch": round(alg_bytes),
+                "launches": nl, "avg_launch_ms": round(sec / max(nl, 1) * 1e3, 4),
+                "share_of_step": round(sec / elapsed, 3)}
+    # critic stack (BASELINE target: >= 40 % MFMA utilisation; SURVEY 8(d): 10.4*Cf*B / t_critic_kernels): EVERY kernel of
+    # the critic -- conv forward / data / weight gradients of its 8 layers incl. the HBM-bound 2-channel first layer, the
+    # Linear kernels (lin_*), bias/activation and the penalty's elementwise passes (ew_*) -- algorithmic flops (real
+    # channels) / summed launch durations.  `conv_only` is the same without the lin_* / ew_* launches.
+    isc = lambda t: ":C" in t
+    cf = sum(v[0] for t, v in agg.items() if isc(t))
+    cs = sum(v[1] for t, v in agg.items() if isc(t))
+    ccf = sum(v[0] for t, v in agg.items() if isc(t) and t.startswith("conv"))
+    ccs = sum(v[1] for t, v in agg.items() if isc(t) and t.startswith("conv"))
+    critic_stack = {"tflops": round(cf / cs / 1e12, 2) if cs > 0 else None, "mfma_frac": round(cf / cs / 1e12 / peak, 4) if cs > 0 else None,
+                    "share_of_step": round(cs / elapsed, 3),
+                    "conv_only": {"tflops": round(ccf / ccs / 1e12, 2) if ccs > 0 else None,
+                                  "mfma_frac": round(ccf / ccs / 1e12 / peak, 4) if ccs > 0 else None},
+                    "alg_tflop_per_step": round(cf / steps / 1e12, 3)}
+    f8 = [t for t in agg if t.endswith(":k32")]
+    if f8:      # fp8 mode: the MXFP8 conv launches (quantisation of their operands included in the bracketed time)
+        ffl, fsec, fn = sum(agg[t][0] for t in f8), sum(agg[t][1] for t in f8), sum(agg[t][2] for t in f8)
+        roofline["fp8_kernel"] = {"kernel": "gg_halo4w_f8_kernel (MXFP8 conv forward / data gradient of the critic's wide layers, operand "
+                                            "quantisation included; with --dtype fp8 also the generator trunk's forward)", "bound": "mfma", "achieved": round(ffl / fsec / 1e12, 2),
+                                  "peak": MFMA_PEAK_TFLOPS["fp8"], "unit": "TFLOP/s", "frac": round(ffl / fsec / 1e12 / MFMA_PEAK_TFLOPS["fp8"], 4),
+                                  "launches": fn, "share_of_step": round(fsec / elapsed, 3)}
+    return roofline, critic_stack, kernels
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,8 +289,13 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two short extra measurements of the default line (5 steps without per-launch events; 5 steps of the fp8 mode)")
     ap.add_argument("--per-layer", action="store_true", help="diagnostic: split the `kernels` table by layer geometry (with bytes)")
     ap.add_argument("--graphs", action="store_true", help="replay the iterations as captured HIP graphs (small, launch-bound tiles)")
+    ap.add_argument("--check-finite", action="store_true",
+                    help="debug: after every iteration one fused isfinite reduction over the scalars, the gradient buffers and the generated "
+                         "batch; raises naming the first offending buffer (the stand-in for the reference's set_detect_anomaly, wasserstein.py:13)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gradient exchange goes over gloo")
     args = ap.parse_args()
@@ -186,10 +306,7 @@ def main():
         sys.exit(self_launch(args.gpus))
 
     import torch
-    from downgan_amd import synthetic
     from downgan_amd.dist import Dist
-    from downgan_amd.engine import HyperParams, TrainEngine
-    from downgan_amd.ops import HipOps
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
@@ -201,110 +318,65 @@ def main():
     if args.batch:
         B = args.batch
     is_f8 = args.dtype in ("fp8", "fp8c")
-    ops = HipOps("bf16" if is_f8 else args.dtype, f"cuda:{local}", f8_critic=is_f8, f8_generator=args.dtype == "fp8")
-    eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B * world), num_res_blocks=nrb, dist=dist)
-    eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))       # seed 0 on every rank
-    eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
-    coarse, fine = synthetic.tiles(B, cin, S, rank=rank)                      # seed 1234 + rank
-    xc = ops.zeros(B, S, S, eng.G.cin_p); ops.nchw_to_nhwc(torch.from_numpy(coarse).cuda(), xc)
-    xf = ops.zeros(B, 8 * S, 8 * S, eng.G.np_p); ops.nchw_to_nhwc(torch.from_numpy(fine).cuda(), xf)
-    del coarse, fine
-    nsteps = args.warmup + args.steps
-    alphas = [torch.from_numpy(synthetic.alpha(B, s, rank=rank)).cuda() for s in range(nsteps)]
+    extras = world == 1 and not args.no_extras and not args.graphs and not args.per_layer
+    nsteps = args.warmup + args.steps + (5 if extras else 0)
+    ops, eng, xc, xf, alphas = build_engine(args, args.dtype, world, dist, local, rank, nsteps)
+
+    # who is where: every rank reports the device it computes on (audit trail of the first real multi-GPU run)
+    me = {"rank": rank, "local_rank": dist.local_rank if dist else 0, "device": f"cuda:{local}", "device_name": torch.cuda.get_device_name(local),
+          "visible_devices": torch.cuda.device_count(), "pid": os.getpid()}
+    ranks_seen = [me]
+    if dist:
+        ranks_seen = [None] * world
+        torch.distributed.all_gather_object(ranks_seen, me)
 
     if args.graphs:
         eng.enable_graphs(xc, xf)
         args.no_kernel_timing = True          # per-launch events cannot be recorded inside a replayed graph
-    def complete_updates():
-        # the critic's Adam is deferred behind the next generator forward (engine.py); finish it so that exactly the work
-        # of the steps issued so far lies before the synchronisation point
-        eng.C.P.sync(); eng.G.P.sync()
-
     for s in range(args.warmup):
         eng.train_step(xc, xf, alphas[s])
-    # The generator runs every `critic_iterations`-th step.  Align the step counter so that the timed region OPENS with a
-    # generator step: K timed steps then contain ceil(K / critic_iterations) generator iterations for every --steps /
-    # --warmup combination -- never fewer than the long-run share (a 3-step region after 2 warm-up steps would otherwise
-    # hold none and read 25 % too fast).
-    ci = eng.hp.critic_iterations
-    eng.num_steps = -(-eng.num_steps // ci) * ci
-    gen_steps_timed = -(-args.steps // ci)
-    complete_updates()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if not args.no_kernel_timing:
-        ops.prof = []
-        ops.per_layer = args.per_layer
-    t0 = time.perf_counter()
-    for s in range(args.warmup, nsteps):
-        eng.train_step(xc, xf, alphas[s])
-    complete_updates()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        t = t if args.rehearse_on_one_gpu else t.cuda()
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    gen_steps_timed = -(-args.steps // eng.hp.critic_iterations)
+    elapsed, prof = timed_steps(eng, ops, xc, xf, alphas, args.warmup, args.steps, dist, args.rehearse_on_one_gpu,
+                                not args.no_kernel_timing, args.per_layer)
     scal = eng.read_scalars(True)
+    peak = MFMA_PEAK_TFLOPS["bf16" if is_f8 else args.dtype]      # gg_halo4w_kernel is a bf16 / fp32 kernel in every mode
+    roofline, critic_stack, kernels = summarise_kernels(prof, elapsed, args.steps, peak, args, args.per_layer)
+    hbm_peak = torch.cuda.max_memory_allocated()
+    stacked = bool(eng.stacked)
 
-    roofline = None
-    critic_stack = None
-    kernels = {}
-    if ops.prof:
-        agg = {}
-        for tag, flops, nbytes, s_ev, e_ev in ops.prof:
-            a = agg.setdefault(tag, [0.0, 0.0, 0, 0.0])
-            a[0] += flops; a[1] += s_ev.elapsed_time(e_ev) * 1e-3; a[2] += 1; a[3] += nbytes
-        for tag, (fl, sec, n, nb_) in agg.items():
-            kernels[tag] = {"launches": n, "seconds": round(sec, 4), "tflops": round(fl / sec / 1e12, 2) if sec > 0 else None}
-            if args.per_layer:
-                kernels[tag]["alg_tbps"] = round(nb_ / sec / 1e12, 2) if sec > 0 else None
-        # dominant kernel: gg_halo4w_kernel (conv forward of both strides + data gradients; two instantiations).  Only calls that were
-        # served by that kernel alone (tag suffix k8) are counted, so achieved = algorithmic flops of those
-        # launches / their summed launch durations, and launches/seconds give the average launch duration.
-        halo = [t for t in agg if t.endswith(":k8")]
-        fl = sum(agg[t][0] for t in halo)
-        sec = sum(agg[t][1] for t in halo)
-        nl = sum(agg[t][2] for t in halo)
-        peak = MFMA_PEAK_TFLOPS["bf16" if is_f8 else args.dtype]      # gg_halo4w_kernel is a bf16 / fp32 kernel in every mode
-        ach = fl / sec / 1e12 if sec > 0 else 0.0
-        alg_bytes = sum(agg[t][3] for t in halo) / max(nl, 1)
-        traffic, traffic_src = pmc_traffic("gg_halo4w_kernel", args)
-        roofline = {"kernel": "gg_halo4w_kernel (implicit-GEMM conv3x3: forward, stride 1 and 2, and data gradients)", "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "alg_bytes_per_launch": round(alg_bytes),
-                    "launches": nl, "avg_launch_ms": round(sec / max(nl, 1) * 1e3, 4),
-                    "share_of_step": round(sec / elapsed, 3)}
-        # critic stack (BASELINE target: >= 40 % MFMA utilisation; SURVEY 8(d): 10.4*Cf*B / t_critic_kernels): EVERY kernel of
-        # the critic -- conv forward / data / weight gradients of its 8 layers incl. the HBM-bound 2-channel first layer, the
-        # Linear kernels (lin_*), bias/activation and the penalty's elementwise passes (ew_*) -- algorithmic flops (real
-        # channels) / summed launch durations.  `conv_only` is the same without the lin_* / ew_* launches.
-        isc = lambda t: ":C" in t
-        cf = sum(v[0] for t, v in agg.items() if isc(t))
-        cs = sum(v[1] for t, v in agg.items() if isc(t))
-        ccf = sum(v[0] for t, v in agg.items() if isc(t) and t.startswith("conv"))
-        ccs = sum(v[1] for t, v in agg.items() if isc(t) and t.startswith("conv"))
-        critic_stack = {"tflops": round(cf / cs / 1e12, 2) if cs > 0 else None, "mfma_frac": round(cf / cs / 1e12 / peak, 4) if cs > 0 else None,
-                        "share_of_step": round(cs / elapsed, 3),
-                        "conv_only": {"tflops": round(ccf / ccs / 1e12, 2) if ccs > 0 else None,
-                                      "mfma_frac": round(ccf / ccs / 1e12 / peak, 4) if ccs > 0 else None},
-                        "alg_tflop_per_step": round(cf / args.steps / 1e12, 3)}
-        f8 = [t for t in agg if t.endswith(":k32")]
-        if f8:      # fp8 mode: the MXFP8 conv launches (quantisation of their operands included in the bracketed time)
-            ffl, fsec, fn = sum(agg[t][0] for t in f8), sum(agg[t][1] for t in f8), sum(agg[t][2] for t in f8)
-            roofline["fp8_kernel"] = {"kernel": "gg_halo4w_f8_kernel (MXFP8 conv forward / data gradient of the critic's wide layers, operand "
-                                                "quantisation included; with --dtype fp8 also the generator trunk's forward)", "bound": "mfma", "achieved": round(ffl / fsec / 1e12, 2),
-                                      "peak": MFMA_PEAK_TFLOPS["fp8"], "unit": "TFLOP/s", "frac": round(ffl / fsec / 1e12 / MFMA_PEAK_TFLOPS["fp8"], 4),
-                                      "launches": fn, "share_of_step": round(fsec / elapsed, 3)}
-        ops.prof = None
+    # ---- extras of the default line (single GPU): the same engine without the per-launch events, then the fp8 mode
+    bare = fp8 = None
+    if extras:
+        if not args.no_kernel_timing:
+            e2, _ = timed_steps(eng, ops, xc, xf, alphas, args.warmup + args.steps, 5, None, False, False, False)
+            bare = {"steps": 5, "ms_per_step": round(e2 / 5 * 1e3, 2), "value": round(5 * B / e2, 4), "unit": "samples/s",
+                    "what": "5 more steps of the same engine WITHOUT the per-launch HIP events that `kernels` / `roofline` come from "
+                            "(`value` is the event-instrumented region, the conservative one)"}
+        if args.dtype == "bf16" and args.workload in ("cfg2", "mid") and not args.check_finite:
+            # BASELINE configs[4] (fp8 conv path) made visible to the default command: free the bf16 engine, build the fp8 one,
+            # 1 warm-up + 5 timed steps (one generator step among them, as in the long run).  Not `value`.
+            del eng, ops, xc, xf, alphas
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            ops8, eng8, xc8, xf8, al8 = build_engine(args, "fp8", 1, None, local, 0, 6)
+            eng8.train_step(xc8, xf8, al8[0])
+            e8, prof8 = timed_steps(eng8, ops8, xc8, xf8, al8, 1, 5, None, False, True, False)
+            sc8 = eng8.read_scalars(True)
+            r8, cs8, _ = summarise_kernels(prof8, e8, 5, MFMA_PEAK_TFLOPS["bf16"], args, False, with_traffic=False)
+            fp8 = {"what": "--dtype fp8 (BASELINE configs[4]: MXFP8 MFMA for the critic's wide convs forward + data gradient and the generator trunk's "
+                           "forward; weight gradients / tail / Linear / Adam as in bf16), same workload, 1 warm-up + 5 timed steps",
+                   "value": round(5 * B / e8, 4), "unit": "samples/s", "steps": 5, "ms_per_step": round(e8 / 5 * 1e3, 2),
+                   "vs_bf16": round((5 * B / e8) / (args.steps * B / elapsed), 4),
+                   "roofline": (r8 or {}).get("fp8_kernel"), "critic_stack_frac_of_bf16_peak": (cs8 or {}).get("mfma_frac"),
+                   "losses": {k: sc8[k] for k in ("critic_loss", "gp_ret", "g_loss") if k in sc8},
+                   "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+            del eng8, ops8, xc8, xf8, al8
 
     if rank == 0:
         gf, cf = conv_flops_per_sample(S, F_, cin, 2, nrb)                          # real channels: algorithmic
-        gfp, cfp = conv_flops_per_sample(S, F_, eng.G.cin_p, eng.G.np_p, nrb)       # zero-padded channels: what the MFMAs execute
+        gfp, cfp = conv_flops_per_sample(S, F_, 16 * ((cin + 15) // 16), 16, nrb)   # zero-padded channels: what the MFMAs execute
         value = args.steps * B * world / elapsed
         w_survey = 1.6 * gf + 10.4 * cf        # SURVEY 8(d) necessary work: critic iteration Gf + 10 Cf, generator iteration 3 Gf + 2 Cf
         w_step = 1.4 * gf + 10.4 * cf          # executed: on generator steps ONE G(coarse) serves both iterations (engine.train_step)
@@ -314,21 +386,29 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "rehearsal": bool(args.rehearse_on_one_gpu),
             "config": {"workload": f"{args.workload}: batch {B}/GPU (global {B * world}), {cin}ch {S}x{S}->{8 * S}x{8 * S}, "
                                    f"filters {F_}, {nrb} RRDBs, WGAN-GP critic step every step + generator step every 5th",
                        "parallelism": f"dp{world}", "per_gpu_batch": B, "global_batch": B * world,
+                       "exchange": (None if world == 1 else "gloo over host memory, all ranks on cuda:0 (REHEARSAL: not a multi-GPU measurement)"
+                                    if args.rehearse_on_one_gpu else "RCCL (torch.distributed nccl backend) all-reduce of the flat fp32 gradient buffers"),
                        "alg_tflop_per_sample_step": round(w_step / 1e12, 4),
                        "alg_tflop_per_sample_step_survey": round(w_survey / 1e12, 4),
                        "executed_padded_tflop_per_sample_step": round(w_padded / 1e12, 4),
                        "work": "1.4*Gf + 10.4*Cf per sample-step, real channels (SURVEY 8(d) counts 1.6*Gf: the generator iteration's "
                                "G(coarse) is the critic iteration's, computed once)",
                        "generator_steps_in_timed_region": gen_steps_timed,
-                       "critic_passes_stacked": bool(eng.stacked)},
-            "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-            "step_mfma_frac": round(w_step * value / world / 1e12 / MFMA_PEAK_TFLOPS["bf16" if is_f8 else args.dtype], 4),
+                       "critic_passes_stacked": stacked},
+            "ranks_seen": ranks_seen,
+            "hbm_peak_gib": round(hbm_peak / 2 ** 30, 1),
+            "step_mfma_frac": round(w_step * value / world / 1e12 / peak, 4),
             "losses": {k: scal[k] for k in ("critic_loss", "gp_ret", "g_loss") if k in scal},
             "roofline": roofline, "critic_conv_stack": critic_stack, "kernels": kernels,
         }
+        if bare is not None:
+            out["without_kernel_events"] = bare
+        if fp8 is not None:
+            out["fp8"] = fp8
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, (B, S, F_, cin, nrb))
         print(json.dumps(out), flush=True)

@@ -40,15 +40,37 @@ class WassersteinGAN:
         self.last = {}
         self.metrics_log = []
 
+    check_finite = False         # debug: NaN / Inf census after every iteration (TrainEngine(check_finite=True); the reference
+                                 # runs with torch.autograd.set_detect_anomaly(True), wasserstein.py:13)
+
     def _eng(self, coarse, fine):
+        """The shape-bound native engine for this batch.  A batch of another size (a DataLoader's ragged last batch, a test loader
+        with its own batch size) re-creates it; the master parameters AND both Adam states (m, v, step count) are carried over on
+        the device, so training continues exactly as with one optimizer (stage.py:63-64 builds them once).  The old engine's
+        buffers are released BEFORE the new ones are allocated (cfg2: 142 GiB each)."""
         B, cin, S, _ = coarse.shape
         if self._engine is None or (self._engine.B, self._engine.S) != (B, S):
             assert self.G.dtype == self.C.dtype
+            carry = None
+            if self._engine is not None and self._engine.S == S:
+                old = self._engine
+                carry = (old.G.P.export_state(), old.C.P.export_state())      # flat fp32 buffers only (8.8 GB at cfg2)
+                self.G._bound = self.C._bound = None                          # (no host round trip: the state moves on the device)
+                self._engine = self._stage = old = None
+                import gc
+                gc.collect()
+                if torch.cuda.is_available():
+                    torch.cuda.empty_cache()
             ops = backend.make_ops(self.G.dtype, self.G.device)
             e = TrainEngine(ops, S, self.G.filters, cin, B, hp.as_engine_hp(B), self.G.n_predictands,
-                            self.G.num_res_blocks, self.G.num_upsample, dist=self.dist)
-            self.G.bind(e.G)
-            self.C.bind(e.C)
+                            self.G.num_res_blocks, self.G.num_upsample, dist=self.dist, check_finite=self.check_finite)
+            if carry is not None:
+                e.G.P.import_state(carry[0]); e.C.P.import_state(carry[1])
+                self.G.bind(e.G, load=False); self.C.bind(e.C, load=False)
+                del carry
+            else:
+                self.G.bind(e.G)
+                self.C.bind(e.C)
             self._adopt_optimizers(e)
             e.num_steps = self.num_steps
             self._engine = e
@@ -146,10 +168,14 @@ class WassersteinGAN:
         if self.log_metrics:
             summary["train"] = self._metric_means(train_metrics)                     # :150
             if testdataloader is not None:
-                for data in testdataloader:                                          # :157-168
-                    if data[0].shape[0] == self._engine.B:                           # full batches only (buffers are shape-bound)
-                        test_metrics.append(self.gen_batch_and_log_metrics(data[0], data[1]))
+                # :157-168.  EVERY test batch is evaluated, whatever its size (the engine re-binds, state carried over); the
+                # reference's epoch mean is the mean over batches (post_epoch_metric_mean), a ragged batch counting as one
+                for data in testdataloader:
+                    test_metrics.append(self.gen_batch_and_log_metrics(data[0], data[1]))
+                if not test_metrics:
+                    raise ValueError("the test loader yielded no batch: no test metrics for this epoch (wasserstein.py:157-170)")
                 summary["test"] = self._metric_means(test_metrics)                   # :170
+                summary["test_batches"] = len(test_metrics)
         if self.checkpoint_dir is not None:
             from ..checkpoint import log_network_models
             summary["checkpoints"] = log_network_models(self.C, self.G, epoch, self.checkpoint_dir)   # :178

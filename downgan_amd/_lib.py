@@ -60,6 +60,13 @@ class FieldPlanes(C.Structure):
     _fields_ = [("plane", C.c_void_p * MAX_FIELDS), ("mean", C.c_float * MAX_FIELDS), ("inv_std", C.c_float * MAX_FIELDS), ("c", C.c_int)]
 
 
+FINITE_MAX = 8
+
+
+class FiniteBufs(C.Structure):
+    _fields_ = [("ptr", C.c_void_p * FINITE_MAX), ("n", C.c_int64 * FINITE_MAX), ("dtype", C.c_int * FINITE_MAX), ("nbuf", C.c_int)]
+
+
 MINMAX_PARTS = 256
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
@@ -110,6 +117,9 @@ _PROTOS = {
     "dg_stage_fields": [_i, C.POINTER(FieldPlanes), _i64, _vp, _vp],
     "dg_lowpass5": [_i, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp],
     "dg_lowpass5_adjoint": [_i, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp],
+    "dg_set_deterministic_workspace": [_vp, _i64],
+    "dg_deterministic": [],
+    "dg_count_nonfinite": [C.POINTER(FiniteBufs), _vp, _vp],
 }
 EXPORTS = ["dg_version"] + list(_PROTOS)
 

@@ -105,6 +105,15 @@ static inline int dg_set_max_lds_once(std::atomic<unsigned long long>& done, con
     if (dg_set_max_lds_once(dg_done_, reinterpret_cast<const void*>(kernel), (bytes)) != DG_OK) return DG_ERR_LAUNCH; \
   } while (0)
 
+// Deterministic-reduction mode (debug.hip, dg_set_deterministic_workspace): a launch whose workgroups accumulate partial results
+// into one fp32 target region takes a plan of `copies` zero-filled copies of that region inside the caller's workspace, points
+// workgroup / split / wave c at copy c (DG_DET_PTR: same address arithmetic, other base) and has the copies added to the target in
+// index order afterwards.  ws == nullptr: mode off, or a single copy (unique writers): accumulate into the target directly.
+struct DetPlan { float* ws; long long stride; int copies; };
+bool dg_det_on();
+int dg_det_begin(long long stride, int want, hipStream_t st, DetPlan* p);
+int dg_det_reduce(const DetPlan& p, long long off, float* target, long long n, hipStream_t st);
+
 // bijective XCD-aware remap of a linear block id: blocks that share an XCD (id % 8 equal) get a
 // contiguous range of logical tiles, so neighbouring tiles share that XCD's L2 (speed only).
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {

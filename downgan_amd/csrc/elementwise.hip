@@ -203,8 +203,10 @@ extern "C" int dg_scale_rows(int dtype, const void* g, const float* coef, void* 
 }
 
 // ------------------------------------------------------------------ per-image sum of squares (wave-shuffle reduce)
+// (det_ws / det_stride, here and below: deterministic mode -- block c accumulates into copy c of the target inside the workspace,
+// dg_internal.h DetPlan)
 template <typename T>
-__global__ void sumsq_kernel(const T* g, long long chunks_per_img, float* ss) {
+__global__ void sumsq_kernel(const T* g, long long chunks_per_img, float* ss, float* det_ws, long long det_stride) {
   constexpr int EPC = DT<T>::EPC;
   __shared__ float part[4];
   const int b = blockIdx.y;
@@ -219,7 +221,7 @@ __global__ void sumsq_kernel(const T* g, long long chunks_per_img, float* ss) {
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(ss + b, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) atomicAdd((det_ws ? det_ws + blockIdx.x * det_stride : ss) + b, part[0] + part[1] + part[2] + part[3]);
 }
 extern "C" int dg_sumsq_rows(int dtype, const void* g, int B, int64_t per_img, float* ss, void* stream) {
   if (!g || !ss || B <= 0 || per_img <= 0 || per_img % 8) return DG_ERR_BAD_SHAPE;
@@ -231,11 +233,15 @@ extern "C" int dg_sumsq_rows(int dtype, const void* g, int B, int64_t per_img, f
   if (env_nb && atoi(env_nb) > 0 && atoi(env_nb) < nb) nb = atoi(env_nb);
   const bool u16 = getenv("DG_COLSUM_U16") != nullptr;
   if (nb < 1) nb = 1;
+  if (dtype != DG_F32 && dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  DetPlan plan;
+  if (dg_det_begin(B, (int)nb, st, &plan) != DG_OK) return DG_ERR_LAUNCH;
+  nb = plan.copies;
   dim3 gr((unsigned)nb, B);
-  if (dtype == DG_F32) hipLaunchKernelGGL(sumsq_kernel<float>, gr, dim3(256), 0, st, (const float*)g, per_img / 4, ss);
-  else if (dtype == DG_BF16) hipLaunchKernelGGL(sumsq_kernel<bf16_t>, gr, dim3(256), 0, st, (const bf16_t*)g, per_img / 8, ss);
-  else return DG_ERR_BAD_DTYPE;
-  return dg_check_launch();
+  if (dtype == DG_F32) hipLaunchKernelGGL(sumsq_kernel<float>, gr, dim3(256), 0, st, (const float*)g, per_img / 4, ss, plan.ws, plan.stride);
+  else hipLaunchKernelGGL(sumsq_kernel<bf16_t>, gr, dim3(256), 0, st, (const bf16_t*)g, per_img / 8, ss, plan.ws, plan.stride);
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return dg_det_reduce(plan, 0, ss, B, st);
 }
 
 // n_b = sqrt(ss_b + 1e-12); gp_ret = lambda * mean_b (n_b-1)^2 ; coef_b = weight*lambda*(2/Bglobal)*(n_b-1)/n_b
@@ -260,7 +266,7 @@ extern "C" int dg_gp_finish(const float* ss, int B, int B_global, float gp_lambd
 // ------------------------------------------------------------------ L1 content loss + gradient
 template <typename T, bool SQ>   // SQ: accumulate (a-b)^2 instead of |a-b| (MSE metric); no gradient in that mode
 __global__ void l1_kernel(const T* a, long long lda, const T* b, long long ldb, long long rows, int cchunks, float* acc,
-                          T* grad, long long ldg, float gscale, const T* addend, long long ldadd) {
+                          T* grad, long long ldg, float gscale, const T* addend, long long ldadd, float* det_ws) {
   constexpr int EPC = DT<T>::EPC;
   __shared__ float part[4];
   const long long total = rows * cchunks;
@@ -289,7 +295,7 @@ __global__ void l1_kernel(const T* a, long long lda, const T* b, long long ldb, 
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) atomicAdd(det_ws ? det_ws + blockIdx.x : acc, part[0] + part[1] + part[2] + part[3]);
 }
 extern "C" int dg_l1(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int C, float* acc,
                      void* grad, int64_t ldg, float grad_scale, const void* addend, int64_t ldadd, void* stream) {
@@ -300,10 +306,14 @@ extern "C" int dg_l1(int dtype, const void* a, int64_t lda, const void* b, int64
   long long nb = (rows * (C / epc) + 256 * 8 - 1) / (256 * 8);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
-  if (dtype == DG_F32) hipLaunchKernelGGL((l1_kernel<float, false>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, rows, C / 4, acc, (float*)grad, ldg, grad_scale, (const float*)addend, ldadd);
-  else if (dtype == DG_BF16) hipLaunchKernelGGL((l1_kernel<bf16_t, false>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, rows, C / 8, acc, (bf16_t*)grad, ldg, grad_scale, (const bf16_t*)addend, ldadd);
-  else return DG_ERR_BAD_DTYPE;
-  return dg_check_launch();
+  if (dtype != DG_F32 && dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  DetPlan plan;
+  if (dg_det_begin(1, (int)nb, st, &plan) != DG_OK) return DG_ERR_LAUNCH;
+  nb = plan.copies;
+  if (dtype == DG_F32) hipLaunchKernelGGL((l1_kernel<float, false>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, rows, C / 4, acc, (float*)grad, ldg, grad_scale, (const float*)addend, ldadd, plan.ws);
+  else hipLaunchKernelGGL((l1_kernel<bf16_t, false>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, rows, C / 8, acc, (bf16_t*)grad, ldg, grad_scale, (const bf16_t*)addend, ldadd, plan.ws);
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return dg_det_reduce(plan, 0, acc, 1, st);
 }
 
 extern "C" int dg_sqdiff(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, int64_t rows, int C, float* acc,
@@ -314,16 +324,20 @@ extern "C" int dg_sqdiff(int dtype, const void* a, int64_t lda, const void* b, i
   long long nb = (rows * (C / epc) + 256 * 8 - 1) / (256 * 8);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
-  if (dtype == DG_F32) hipLaunchKernelGGL((l1_kernel<float, true>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, rows, C / 4, acc, (float*)nullptr, 0ll, 0.f, (const float*)nullptr, 0ll);
-  else if (dtype == DG_BF16) hipLaunchKernelGGL((l1_kernel<bf16_t, true>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, rows, C / 8, acc, (bf16_t*)nullptr, 0ll, 0.f, (const bf16_t*)nullptr, 0ll);
-  else return DG_ERR_BAD_DTYPE;
-  return dg_check_launch();
+  if (dtype != DG_F32 && dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  DetPlan plan;
+  if (dg_det_begin(1, (int)nb, st, &plan) != DG_OK) return DG_ERR_LAUNCH;
+  nb = plan.copies;
+  if (dtype == DG_F32) hipLaunchKernelGGL((l1_kernel<float, true>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, rows, C / 4, acc, (float*)nullptr, 0ll, 0.f, (const float*)nullptr, 0ll, plan.ws);
+  else hipLaunchKernelGGL((l1_kernel<bf16_t, true>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, rows, C / 8, acc, (bf16_t*)nullptr, 0ll, 0.f, (const bf16_t*)nullptr, 0ll, plan.ws);
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return dg_det_reduce(plan, 0, acc, 1, st);
 }
 
 // ------------------------------------------------------------------ column sum (bias gradients)
 template <typename T, int UNR>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* dy, long long ld_outer, int rows_inner, long long ld, int rows,
-                                                      int cchunks, int rows_per_block, float* db) {
+                                                      int cchunks, int rows_per_block, float* db, float* det_ws, long long det_stride) {
   // HBM-bound pass: every thread keeps UNR independent 16-byte loads in flight (a one-load-per-iteration loop with a
   // 64-bit division in it ran at 0.6 TB/s)
   constexpr int EPC = DT<T>::EPC;
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* dy, long long ld_o
 #pragma unroll
       for (int e = 0; e < EPC; ++e) s[e] += red[(t * cchunks + tx) * EPC + e];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) atomicAdd(db + tx * EPC + e, s[e]);
+    for (int e = 0; e < EPC; ++e) atomicAdd((det_ws ? det_ws + blockIdx.x * det_stride : db) + tx * EPC + e, s[e]);
   }
 }
 extern "C" int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, int64_t rows_inner, int64_t ld,
@@ -377,12 +391,16 @@ extern "C" int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t 
   long long nb = rows / 256;
   if (nb < 1) nb = 1;
   if (nb > 128) nb = 128;
+  if (dtype != DG_F32 && dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  DetPlan plan;
+  if (dg_det_begin(C, (int)nb, st, &plan) != DG_OK) return DG_ERR_LAUNCH;
+  nb = plan.copies;
   const long long rpb = (rows + nb - 1) / nb;
   nb = (rows + rpb - 1) / rpb;
-  if (dtype == DG_F32) hipLaunchKernelGGL((colsum_kernel<float, 8>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)dy, ld_outer, (int)rows_inner, ld, (int)rows, C / 4, (int)rpb, db);
-  else if (dtype == DG_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t, 8>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy, ld_outer, (int)rows_inner, ld, (int)rows, C / 8, (int)rpb, db);
-  else return DG_ERR_BAD_DTYPE;
-  return dg_check_launch();
+  if (dtype == DG_F32) hipLaunchKernelGGL((colsum_kernel<float, 8>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)dy, ld_outer, (int)rows_inner, ld, (int)rows, C / 4, (int)rpb, db, plan.ws, plan.stride);
+  else hipLaunchKernelGGL((colsum_kernel<bf16_t, 8>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy, ld_outer, (int)rows_inner, ld, (int)rows, C / 8, (int)rpb, db, plan.ws, plan.stride);
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return dg_det_reduce(plan, 0, db, C, st);
 }
 
 // ------------------------------------------------------------------ small head helpers

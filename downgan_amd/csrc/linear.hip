@@ -53,7 +53,7 @@ template <> struct LdX4<bf16_t> {
 template <typename T, int NB, int NO>
 __global__ __launch_bounds__(256) void lin_fwd_kernel(const T* __restrict__ x, long long ldx, const T* __restrict__ w,
                                                       long long ldw, float* y, int ldy, int B, int O, long long K,
-                                                      long long kpw) {
+                                                      long long kpw, float* det_ws, long long det_stride) {
   constexpr int EPC = DT<T>::EPC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long gw = (long long)blockIdx.x * 4 + wave;
@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const T* __restrict__ x, l
 #pragma unroll
         for (int i = 0; i < NB; ++i) MmaL<T>::run(fa[u][j], fb[u][i], acc[j][i]);
   }
+  // deterministic mode (dg_internal.h DetPlan): wave gw accumulates into copy gw of y inside the workspace
+  float* const yp = det_ws ? det_ws + gw * det_stride : y;
 #pragma unroll
   for (int j = 0; j < NO; ++j)
 #pragma unroll
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const T* __restrict__ x, l
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int o = 16 * j + 4 * g + e;
-        if (b < B && o < O) atomicAdd(y + (long long)b * ldy + o, acc[j][i][e]);
+        if (b < B && o < O) atomicAdd(yp + (long long)b * ldy + o, acc[j][i][e]);
       }
     }
 }
@@ -118,10 +120,20 @@ static int lin_fwd_launch(const T* x, long long ldx, const T* w, long long ldw, 
   long long nw = (K + blk - 1) / blk;                  // one interleaved block stream per wave, at most 2048 waves
   if (nw > 2048) nw = 2048;
   nw = (nw + 3) / 4 * 4;
+  // deterministic mode: one copy of the y rows [B][ldy] of this call per wave (the copies hold this call's rows only: y - based offsets)
+  DetPlan plan;
+  const long long region = (long long)(B - 1) * ldy + O;
+  if (dg_det_begin((region + 3) / 4 * 4, (int)nw, st, &plan) != DG_OK) return DG_ERR_LAUNCH;
+  if (dg_det_on()) {                       // (a block is four waves: the workspace must hold at least four copies of the rows)
+    if (!plan.ws || plan.copies < 4) return DG_ERR_BAD_ARG;
+    nw = plan.copies / 4 * 4;
+  }
   const long long kpw = nw;
   const unsigned nb = (unsigned)(nw / 4);
-  hipLaunchKernelGGL((lin_fwd_kernel<T, NB, NO>), dim3(nb), dim3(256), 0, st, x, ldx, w, ldw, y, ldy, B, O, K, kpw);
-  return dg_check_launch();
+  hipLaunchKernelGGL((lin_fwd_kernel<T, NB, NO>), dim3(nb), dim3(256), 0, st, x, ldx, w, ldw, y, ldy, B, O, K, kpw, plan.ws, plan.stride);
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  plan.copies = (int)nw;
+  return dg_det_reduce(plan, 0, y, region, st);
 }
 
 template <typename T>

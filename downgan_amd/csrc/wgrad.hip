@@ -26,7 +26,12 @@ struct WGArgs {
   // to conv t+1's own gradient (row stride 9 * (t + 1) * 128) / bias gradient
   int tri;
   float* dwk[8]; float* dbk[8];
+  // deterministic mode (dg_internal.h DetPlan): split `by` accumulates into copy `by` of the target region inside the workspace
+  // instead of the gradient itself: dw / dwk[] / dbk[] keep their offsets from det_base, db sits at det_db_off of the copy
+  float* det_ws; const float* det_base; long long det_stride, det_db_off;
 };
+#define WG_DET_PTR(a, p, by) ((a).det_ws ? (a).det_ws + (long long)(by) * (a).det_stride + ((p) - (a).det_base) : (p))
+#define WG_DET_DB(a, by) ((a).det_ws ? (a).det_ws + (long long)(by) * (a).det_stride + (a).det_db_off : (a).db)
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
@@ -296,6 +301,8 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
 
   // D[row = co][col = ci]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const long long ldw = 9ll * a.Cin;
+  float* const dwp = WG_DET_PTR(a, a.dw, by);
+  float* const dbp = a.db ? WG_DET_DB(a, by) : nullptr;
 #pragma unroll
   for (int i = 0; i < FA; ++i)
 #pragma unroll
@@ -306,11 +313,11 @@ __global__ __launch_bounds__(256) void wg_kernel(const WGArgs a) {
         const int co = co0 + wco * (BCO / 2) + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         if constexpr (IM2COL) {
           if (co < a.Cout) {
-            if (ci < 18) atomicAdd(a.dw + (long long)co * ldw + (ci >> 1) * a.Cin + (ci & 1), acc[i][j][reg]);
-            else if (ci == 18 && a.db) atomicAdd(a.db + co, acc[i][j][reg]);
+            if (ci < 18) atomicAdd(dwp + (long long)co * ldw + (ci >> 1) * a.Cin + (ci & 1), acc[i][j][reg]);
+            else if (ci == 18 && dbp) atomicAdd(dbp + co, acc[i][j][reg]);
           }
         } else {
-          if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (long long)co * ldw + tap * a.Cin + ci, acc[i][j][reg]);
+          if (co < a.Cout && ci < a.Cin) atomicAdd(dwp + (long long)co * ldw + tap * a.Cin + ci, acc[i][j][reg]);
         }
       }
     }
@@ -329,6 +336,39 @@ static int wg_pick_splits(int ntiles, long long target, long long cap, int Mpix,
   if (splits < 1) splits = 1;
   *ppb = ((Mpix + splits - 1) / splits + 63) / 64 * 64;
   return (Mpix + *ppb - 1) / *ppb;
+}
+
+// Deterministic mode: plan `splits` copies of the launch's target region -- [dw | db] (Cout * 9 * Cin + Cout floats), or in dense-block
+// mode the span of the flat gradient buffer that holds the block's weight and bias gradients -- and return the split count granted.
+static int wg_det_begin(WGArgs& a, int splits, hipStream_t st, DetPlan* p, float** lo_out, long long* span_out) {
+  p->ws = nullptr; p->copies = splits;
+  if (!dg_det_on()) return splits;
+  float* lo = a.dw; float* hi = a.dw + (long long)a.Cout * 9 * a.Cin;
+  if (a.tri) {
+    lo = hi = nullptr;
+    long long sum = 0;
+    const int n = a.Cout / 128;
+    for (int k = 0; k < n; ++k) {
+      float* b = a.dwk[k]; float* e = b + 128ll * 9 * (k + 1) * 128;
+      if (!lo || b < lo) lo = b;
+      if (!hi || e > hi) hi = e;
+      sum += e - b;
+      if (a.dbk[k]) { if (a.dbk[k] < lo) lo = a.dbk[k]; if (a.dbk[k] + 128 > hi) hi = a.dbk[k] + 128; sum += 128; }
+    }
+    if (hi - lo > 2 * sum) { p->copies = 1; return 1; }     // gradients scattered over the address space: one split, unique writers
+  }
+  const long long span = hi - lo;
+  const long long stride = (span + (a.tri ? 0 : a.Cout) + 3) / 4 * 4;
+  if (dg_det_begin(stride, splits, st, p) != DG_OK) return -1;
+  if (p->ws) { a.det_ws = p->ws; a.det_base = lo; a.det_stride = stride; a.det_db_off = span; }
+  *lo_out = lo; *span_out = span;
+  return p->copies;
+}
+static int wg_det_end(const WGArgs& a, const DetPlan& p, float* lo, long long span, hipStream_t st) {
+  if (!p.ws) return DG_OK;
+  int rc = dg_det_reduce(p, 0, lo, span, st);
+  if (rc == DG_OK && !a.tri && a.db) rc = dg_det_reduce(p, a.det_db_off, a.db, a.Cout, st);
+  return rc;
 }
 
 // resident workgroups per CU of a kernel instance (LDS- or register-limited), for sizing launches in whole rounds
@@ -359,10 +399,15 @@ static int wg_launch_im2col(WGArgs& a, hipStream_t st) {
   if (splits < 1) splits = 1;
   a.ppb = ((a.Mpix + splits - 1) / splits + 31) / 32 * 32;
   splits = (a.Mpix + a.ppb - 1) / a.ppb;
+  DetPlan plan; float* lo = nullptr; long long span = 0;
+  const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
+  if (granted < 0) return DG_ERR_LAUNCH;
+  if (granted != splits) { a.ppb = ((a.Mpix + granted - 1) / granted + 31) / 32 * 32; splits = (a.Mpix + a.ppb - 1) / a.ppb; }
   dim3 grid(nco_t, splits);
   if (big_co) hipLaunchKernelGGL((wg_kernel<T, 128, 64, true, 32, true>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((wg_kernel<T, 64, 64, true, 32, true>), grid, dim3(256), lds, st, a);
-  return dg_check_launch();
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return wg_det_end(a, plan, lo, span, st);
 }
 
 template <typename T>
@@ -385,6 +430,7 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   static const bool want_kp64 = getenv("DG_WG_KP64") != nullptr;
   const bool kp64 = rs && want_kp64 && a.Wo % 64 == 0 && sizeof(T) == 2;                 // (ppb is a multiple of 64)
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
+  DetPlan plan; float* lo = nullptr; long long span = 0;
 #define WG_LAUNCH1(BCO, BCI, RS, KPV)                                                                 \
   do {                                                                                                \
     const int lds = 2 * KPV * (BCO + BCI + 2 * PADE) * (int)sizeof(T);                                \
@@ -394,7 +440,10 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
     if (!occ) { occ = wg_resident(wg_kernel<T, BCO, BCI, RS, KPV>, lds); occ_cache.store(occ, std::memory_order_relaxed); } \
     /* 3 rounds of the resident slots, 2 when more than 3 workgroups share a CU */                    \
     const long long target = target_blocks ? target_blocks : (long long)(occ > 3 ? 2 : 3) * 256 * occ; \
-    const int splits = wg_pick_splits(ntiles, target, cap, a.Mpix, &a.ppb);                           \
+    int splits = wg_pick_splits(ntiles, target, cap, a.Mpix, &a.ppb);                                 \
+    const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);                               \
+    if (granted < 0) return DG_ERR_LAUNCH;                                                            \
+    if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb); \
     dim3 grid(ntiles, splits);                                                                        \
     hipLaunchKernelGGL((wg_kernel<T, BCO, BCI, RS, KPV>), grid, dim3(256), lds, st, a);               \
   } while (0)
@@ -410,7 +459,8 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   else WG_LAUNCH(64, 64);
 #undef WG_LAUNCH
 #undef WG_LAUNCH1
-  return dg_check_launch();
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return wg_det_end(a, plan, lo, span, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -589,6 +639,7 @@ __global__ __launch_bounds__(256, 3) void wg3_kernel(const WGArgs a) {
   }
 
   const long long ldw = 9ll * a.Cin;
+  float* const dwp = WG_DET_PTR(a, a.dw, by);
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     const int tap = trow * 3 + s;
@@ -600,7 +651,7 @@ __global__ __launch_bounds__(256, 3) void wg3_kernel(const WGArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int co = co0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (long long)co * ldw + tap * a.Cin + ci, acc[s][i][j][reg]);
+          if (co < a.Cout && ci < a.Cin) atomicAdd(dwp + (long long)co * ldw + tap * a.Cin + ci, acc[s][i][j][reg]);
         }
       }
   }
@@ -614,12 +665,17 @@ static int wg3_launch(WGArgs& a, hipStream_t st) {
   const int ntiles = nco_t * 3 * a.nci_t;
   const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
   const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
-  const int splits = wg_pick_splits(ntiles, 2304, cap, a.Mpix, &a.ppb);             // 3 rounds of 768 slots (3 per CU)
+  int splits = wg_pick_splits(ntiles, 2304, cap, a.Mpix, &a.ppb);                   // 3 rounds of 768 slots (3 per CU)
+  DetPlan plan; float* lo = nullptr; long long span = 0;
+  const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
+  if (granted < 0) return DG_ERR_LAUNCH;
+  if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb);
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
   const int lds = 2 * (32 * (BCO + PADE) + 34 * (BCI + PADE)) * (int)sizeof(T);
   if (lds > 65536) DG_SET_MAX_LDS_ONCE((&wg3_kernel<T, BCO>), lds);
   hipLaunchKernelGGL((wg3_kernel<T, BCO>), dim3(ntiles, splits), dim3(256), lds, st, a);
-  return dg_check_launch();
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return wg_det_end(a, plan, lo, span, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -748,7 +804,8 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
 
   // bias gradient (column sums of the adjoint) on the side: the workgroups of the centre tap row and first input-channel
   // tile already hold every adjoint fragment in registers; wave 0 adds them up (a lane's 8 values belong to one channel)
-  float* const db_out = a.tri ? a.dbk[co_t] : (a.db ? a.db + co0 : nullptr);       // bias gradient of this adjoint tile's rows
+  float* const db_out = a.tri ? (a.dbk[co_t] ? WG_DET_PTR(a, a.dbk[co_t], by) : nullptr)
+                              : (a.db ? WG_DET_DB(a, by) + co0 : nullptr);         // bias gradient of this adjoint tile's rows
   const bool do_db = db_out != nullptr && trow == 1 && ci_t == 0 && wave == 0;
   float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -825,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   // epilogue: one lane-constant 32-bit offset, everything else of an element's address is workgroup-uniform (scalar base)
   const int cin_w = a.tri ? (co_t + 1) * BCI : a.Cin;                  // input channels of the conv these rows belong to
   const int cow0 = a.tri ? 0 : co0;                                    // first gradient row of this tile inside that conv
-  float* const dw_out = a.tri ? a.dwk[co_t] : a.dw;
+  float* const dw_out = WG_DET_PTR(a, a.tri ? a.dwk[co_t] : a.dw, by);
   const long long ldw = 9ll * cin_w;
   const int ci = ci0 + wave * 32 + r32;
   const unsigned lane_off = (unsigned)((((long long)cow0 + 4 * h) * ldw + ci) * 4);
@@ -854,11 +911,16 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
   const double flops = 2.0 * 9 * BCO * (double)BCI * npairs * a.Mpix;
   const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
   static const int tb_env = getenv("DG_WG_TB") ? atoi(getenv("DG_WG_TB")) : 1536;
-  const int splits = wg_pick_splits(ntiles, tb_env, cap, a.Mpix, &a.ppb);           // 3 rounds of 512 slots (2 per CU)
+  int splits = wg_pick_splits(ntiles, tb_env, cap, a.Mpix, &a.ppb);                 // 3 rounds of 512 slots (2 per CU)
+  DetPlan plan; float* lo = nullptr; long long span = 0;
+  const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
+  if (granted < 0) return DG_ERR_LAUNCH;
+  if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb);
   constexpr int lds = 3 * (32 * 256 + (S2 ? 68 : 36) * 256);
   if (lds > 65536) DG_SET_MAX_LDS_ONCE((&wg3w_kernel<S2>), lds);
   hipLaunchKernelGGL((wg3w_kernel<S2>), dim3(ntiles, splits), dim3(256), lds, st, a);
-  return dg_check_launch();
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return wg_det_end(a, plan, lo, span, st);
 }
 
 extern "C" int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, int64_t rows_inner, int64_t ld, int C,

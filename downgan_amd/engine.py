@@ -161,6 +161,20 @@ class ParamStore:
         self.p.copy_(host)
         self.refresh()
 
+    def export_state(self):
+        """(p, m, v, t): the flat master parameters and Adam state (device tensors, by reference) for ``import_state`` of another
+        store of the same network -- the layout of the flat buffer does not depend on the batch size."""
+        self.sync()
+        return self.p, self.m, self.v, self.t
+
+    def import_state(self, state):
+        p, m, v, t = state
+        assert p.numel() == self.size, (p.numel(), self.size)
+        self.sync()
+        self.p.copy_(p); self.m.copy_(m); self.v.copy_(v)
+        self.t = int(t)
+        self.refresh()
+
     def to_host(self, buf=None):
         self.sync()
         h = (self.p if buf is None else buf).detach().cpu()
@@ -776,8 +790,12 @@ class TrainEngine:
     SCALARS = ("c_real_mean", "c_fake_mean", "gp_ret", "g_c_fake_mean", "l1_sum")
 
     def __init__(self, ops, coarse_side, filters, channels, batch, hp: HyperParams = None, n_predictands=2,
-                 num_res_blocks=16, num_upsample=3, dist=None, stacked=None):
+                 num_res_blocks=16, num_upsample=3, dist=None, stacked=None, check_finite=False):
         self.ops, self.hp = ops, hp or HyperParams()
+        # debug mode: after every iteration ONE fused census of NaN / Inf over the scalars, the flat gradient buffer and the
+        # generated batch; raises naming the first offending buffer.  The reference switches torch's anomaly detection on globally
+        # (wasserstein.py:13: a NaN check behind every autograd op, 1.7x slower on the CPU); off by default here.
+        self.check_finite = bool(check_finite)
         self.B, self.S = batch, coarse_side
         self.dist = dist
         self.world = dist.world_size if dist is not None else 1
@@ -860,6 +878,22 @@ class TrainEngine:
         else:
             P.adam_step(self.adam_hp.get(id(P), self.hp), 1.0)
 
+    def _assert_finite(self, where, P, extra=()):
+        """check_finite mode: raise FloatingPointError naming the first buffer of this iteration that holds a NaN / Inf."""
+        if not self.check_finite:
+            return
+        bufs = [("loss scalars", self.scal), (f"{where} gradients (flat buffer)", P.g), ("generated batch G(coarse)", self.G.fake)] + list(extra)
+        counts = self.ops.count_nonfinite(bufs)
+        bad = [(n, c) for n, c in counts.items() if c]
+        if bad:
+            detail = ""
+            if bad[0][0].endswith("(flat buffer)"):      # name the parameters (host side, only on failure)
+                g = P.g.detach().float().cpu()
+                names = [k for k, (off, n, _) in P.entries.items() if not bool(torch.isfinite(g[off:off + n]).all())]
+                detail = f"; parameters: {names[:6]}{' ...' if len(names) > 6 else ''}"
+            raise FloatingPointError(f"check_finite: step {self.num_steps}, {where} iteration: {bad[0][1]} non-finite values in '{bad[0][0]}'"
+                                     f"{detail} (all counts: {counts})")
+
     def critic_iteration(self, coarse, fine, alpha, apply_update=True, save_g=False):
         """wasserstein.py:27-55.  coarse/fine: native NHWC tensors; alpha: fp32 [B] on the device
         (replaces torch.rand at :91).  The generator runs forward-only: its backward in the reference's
@@ -897,6 +931,7 @@ class TrainEngine:
         C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, fc1_slot=s2)   # :40,:87-117
         if C.fc1_fused:
             C.fc1_flush()
+        self._assert_finite("critic", C.P, [("dC/dx-hat", self.gbuf)])
         if apply_update:
             self._allreduce_and_step(C.P, defer=True)             # :52-55 (overlaps with the next generator forward)
 
@@ -918,6 +953,7 @@ class TrainEngine:
         C.backward_stacked(self.x3, (-1.0 / bg, 1.0 / bg, 1.0), self.gbuf)            # d(-mean c_real + mean c_fake), dC/dx-hat
         C.gp_tangent(self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, 2 * B, 2)   # :40, :110-117
         C.fc1_flush()
+        self._assert_finite("critic", C.P, [("dC/dx-hat", self.gbuf)])
         if apply_update:
             self._allreduce_and_step(C.P, defer=True)                                 # :52-55
 
@@ -938,6 +974,7 @@ class TrainEngine:
         o.l1(fake, fine, self._sc("l1_sum"), grad=self.dfake, grad_scale=hp.content_lambda / (self.n_real_elems * self.world),
              addend=self.gbuf)                                    # :78 + losses.py:51-53
         G.backward(coarse, self.dfake)                            # :80
+        self._assert_finite("generator", G.P, [("d loss / d fake", self.dfake)])
         if apply_update:
             self._allreduce_and_step(G.P, defer=True)             # :83 (overlaps with the next critic iteration's real pass)
 
@@ -980,6 +1017,7 @@ class TrainEngine:
         (2ch 16x16 -> 128x128, hyperparams.py:18 / config.py:112) is launch-bound without this."""
         o = self.ops
         assert o.prof is None, "kernel timing hooks record events; disable them before capturing"
+        assert not self.check_finite, "check_finite reads a counter back every iteration: not capturable"
         self._g_coarse, self._g_fine = coarse.clone(), fine.clone()
         side = torch.cuda.Stream(device=o.device)
         side.wait_stream(torch.cuda.current_stream(o.device))
@@ -1074,6 +1112,7 @@ class TrainEngineFS(TrainEngine):
         C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, fc1_slot=s2)
         if C.fc1_fused:
             C.fc1_flush()
+        self._assert_finite("critic", C.P, [("dC/dx-hat", self.gbuf)])
         if apply_update:
             self._allreduce_and_step(C.P, defer=True)             # :57-60
 
@@ -1100,5 +1139,6 @@ class TrainEngineFS(TrainEngine):
         o.lowpass5_adjoint(self.tbuf, self.dfake)
         o.axpby(self.dfake, self.dfake, 1.0, self.gbuf, 1.0)       # + d_high
         G.backward(coarse, self.dfake)                            # :88
+        self._assert_finite("generator", G.P, [("d loss / d fake", self.dfake)])
         if apply_update:
             self._allreduce_and_step(G.P, defer=True)             # :91

@@ -31,9 +31,18 @@ class Critic(NativeModule):
             self._sd = self._bound.state_dict()
         return {k: v.clone() for k, v in self._sd.items()}
 
-    def bind(self, native: NativeCritic):
-        native.load_state_dict(self.state_dict())
+    def bind(self, native: NativeCritic, load=True):
+        """Hand the live parameters to a TrainEngine's network; ``load=False``: the engine already holds them (state carried over
+        from the engine it replaces)."""
+        if load:
+            native.load_state_dict(self.state_dict())
         self._bound = native
+
+    def unbind(self):
+        """Take the parameters back (host copy) and drop the reference to the engine's network, so its buffers can be freed."""
+        if self._bound is not None:
+            self._sd = self._bound.state_dict()
+            self._bound = None
 
     def _get(self, B):
         if self._bound is not None and self._bound.B == B:

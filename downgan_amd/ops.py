@@ -67,8 +67,14 @@ class HipOps:
 
     name = "hip"
 
-    def __init__(self, dtype="bf16", device="cuda:0", f8_critic=False, f8_generator=False):
-        """``f8_critic``: MXFP8 conv path (BASELINE configs[4]) -- forward and data-gradient convs of critic layers whose
+    def __init__(self, dtype="bf16", device="cuda:0", f8_critic=False, f8_generator=False, deterministic=None, det_workspace_mb=512):
+        """``deterministic`` (default: the environment variable DG_DETERMINISTIC): run-to-run bit-identical results.  The split-K
+        weight gradients and the small reductions accumulate with fp32 atomics whose order varies between runs; in this mode they
+        write their partials into a workspace this object owns (``det_workspace_mb``) and add them in a fixed order
+        (csrc/debug.hip, dg_set_deterministic_workspace).  The switch is process-wide in the library: the last HipOps created with
+        ``deterministic=True`` owns it until ``close()`` / garbage collection.
+
+        ``f8_critic``: MXFP8 conv path (BASELINE configs[4]) -- forward and data-gradient convs of critic layers whose
         reduction channels are a multiple of 128 run on the block-scaled fp8 MFMA: their bf16 source tensor and weight pack are
         quantised on the fly (``dg_quant_mxfp8``) unless the caller passes producer-written forms, accumulation is fp32, outputs /
         masks / weight gradients stay bf16.  ``f8_generator`` (implies ``f8_critic``): also the FORWARD of the generator's
@@ -87,6 +93,40 @@ class HipOps:
         self.f8_generator = bool(f8_generator)
         assert not self.f8 or dtype == "bf16", "the fp8 conv path quantises bf16 tensors"
         self._f8_scratch = {}
+        if deterministic is None:
+            deterministic = os.environ.get("DG_DETERMINISTIC", "0") not in ("", "0")
+        self.deterministic = bool(deterministic)
+        self._det_ws = None
+        if self.deterministic:
+            self._det_ws = torch.empty(int(det_workspace_mb) << 20, dtype=torch.uint8, device=self.device)
+            check(self.lib.dg_set_deterministic_workspace(C.c_void_p(self._det_ws.data_ptr()), self._det_ws.numel()), "dg_set_deterministic_workspace")
+        self._finite_counts = None
+
+    def close(self):
+        """Give the library's deterministic-mode workspace back (no-op otherwise)."""
+        if self._det_ws is not None:
+            self.lib.dg_set_deterministic_workspace(C.c_void_p(0), 0)
+            self._det_ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def count_nonfinite(self, bufs):
+        """bufs: [(name, tensor)] (<= 8; fp32 or the compute dtype, contiguous storage ranges) -> {name: number of NaN / Inf elements},
+        ONE launch and one read-back (dg_count_nonfinite): the per-iteration stand-in for set_detect_anomaly (wasserstein.py:13)."""
+        assert 1 <= len(bufs) <= _lib.FINITE_MAX
+        f = _lib.FiniteBufs(nbuf=len(bufs))
+        for i, (name, t) in enumerate(bufs):
+            assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16), (name, t.dtype)
+            f.ptr[i], f.n[i], f.dtype[i] = t.data_ptr(), t.numel(), (_lib.DG_F32 if t.dtype == torch.float32 else _lib.DG_BF16)
+        if self._finite_counts is None:
+            self._finite_counts = torch.zeros(_lib.FINITE_MAX, dtype=torch.int32, device=self.device)
+        check(self.lib.dg_count_nonfinite(C.byref(f), _ptr(self._finite_counts), self._stream()), "dg_count_nonfinite")
+        counts = self._finite_counts.cpu().tolist()
+        return {name: int(counts[i]) for i, (name, _) in enumerate(bufs)}
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):

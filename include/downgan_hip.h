@@ -357,6 +357,28 @@ int dg_lowpass5(int dtype, const void* x, int64_t ldx, int N, int H, int W, int 
 int dg_lowpass5_adjoint(int dtype, const void* g, int64_t ldg, int N, int H, int W, int C, void* out, int64_t ldo,
                         void* stream);
 
+/* ---- debugging aids (off by default; csrc/debug.hip) ----------------------------------------------------------------
+ * dg_set_deterministic_workspace: the split-K weight gradients (dg_conv3x3_wgrad, _wgrad_dense) and the small reductions
+ *   (dg_colsum, dg_sumsq_rows, dg_l1, dg_sqdiff, dg_linear_fwd) accumulate partial results with fp32 atomics, whose order -- and
+ *   so the last bits of every gradient -- differs from run to run.  With a caller-owned device workspace registered here
+ *   (>= 1 MiB, 16-byte aligned; NULL switches the mode off again) each of those launches writes its partials side by side into
+ *   the workspace and adds them to the target in a fixed order: results are bit-identical between runs.  Process-wide; the
+ *   workspace must stay alive while registered and serves one stream at a time.  A launch that needs more room than the
+ *   workspace has runs with fewer splits (slower, same guarantee).
+ * dg_count_nonfinite: counts[i] = number of NaN / Inf elements of buffer i -- the stand-in for the reference's global
+ *   torch.autograd.set_detect_anomaly(True) (DoWnGAN/GAN/wasserstein.py:13), run once per iteration by
+ *   TrainEngine(check_finite=True) instead of after every op. */
+#define DG_FINITE_MAX 8
+typedef struct dg_finite_bufs {
+  const void* ptr[DG_FINITE_MAX];
+  int64_t n[DG_FINITE_MAX];      /* elements */
+  int dtype[DG_FINITE_MAX];      /* DG_F32 or DG_BF16 */
+  int nbuf;
+} dg_finite_bufs;
+int dg_set_deterministic_workspace(void* ws, int64_t bytes);
+int dg_deterministic(void);      /* 1 while a workspace is registered */
+int dg_count_nonfinite(const dg_finite_bufs* bufs, uint32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,14 @@ class EmuOps:
         self.device = torch.device(device)
         self.lib = _lib.lib()
 
+    deterministic = True      # torch-CPU reductions: nothing to switch
+
+    def close(self):
+        pass
+
+    def count_nonfinite(self, bufs):
+        return {name: int((~torch.isfinite(t.float())).sum()) for name, t in bufs}
+
     # ------------------------------------------------------------------ conv family
     def out_shape(self, cv: Conv):
         if cv.pixel_shuffle:

@@ -54,6 +54,13 @@ def test_null_and_shape_errors_do_not_launch():
     assert lib.dg_conv3x3_wgrad(C.byref(g), None, None, None, None, None) == -3
     assert lib.dg_linear_fwd(_lib.DG_BF16, None, 0, None, 0, None, 0, 1, 16, 32, None) == -3
     assert lib.dg_adam(None, None, None, None, None, 16, 1e-3, 0.9, 0.99, 1e-8, 1, 1.0, None) == -3
+    # debugging aids: argument validation only (no device memory is touched)
+    assert lib.dg_deterministic() == 0
+    assert lib.dg_set_deterministic_workspace(C.c_void_p(0x1000), 64) == -3          # below the 1 MiB minimum
+    assert lib.dg_set_deterministic_workspace(C.c_void_p(0x1008), 1 << 21) == -3     # not 16-byte aligned
+    assert lib.dg_set_deterministic_workspace(None, 0) == 0 and lib.dg_deterministic() == 0
+    assert lib.dg_count_nonfinite(None, None, None) == -3
+    assert lib.dg_count_nonfinite(C.byref(_lib.FiniteBufs(nbuf=9)), C.c_void_p(16), None) == -3
 
 
 def test_integration_stub_matches_binding():
@@ -86,7 +93,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pairs = [("dg_epilogue", _lib.Epilogue), ("dg_conv_geom", _lib.ConvGeom), ("dg_gg_desc", _lib.GGDesc),
              ("dg_ssim_params", _lib.SsimParams), ("dg_msssim_combine", _lib.MsssimCombine),
-             ("dg_f8_operands", _lib.F8Operands), ("dg_field_planes", _lib.FieldPlanes)]
+             ("dg_f8_operands", _lib.F8Operands), ("dg_field_planes", _lib.FieldPlanes), ("dg_finite_bufs", _lib.FiniteBufs)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{root}/include/downgan_hip.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -162,3 +162,31 @@ def test_stacked_critic_passes_equal_separate_passes(fs):
     assert abs(t1["g_loss"] - t0["g_loss"]) <= 1e-6 * max(1.0, abs(t0["g_loss"]))
     for k in h0:
         assert float((h1[k] - h0[k]).norm()) <= 1e-5 * float(h0[k].norm()) + 1e-12, k
+
+
+def test_check_finite_names_the_offending_buffer():
+    """TrainEngine(check_finite=True), the per-iteration stand-in for the reference's set_detect_anomaly(True)
+    (wasserstein.py:13): clean iterations pass; a NaN planted in a critic weight / in the fine batch raises a
+    FloatingPointError that names the buffer (and, for gradients, the parameters)."""
+    ops = EmuOps("f32")
+    B, S, F_, cin, nrb = 2, 16, 16, 2, 1
+    eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B), num_res_blocks=nrb, check_finite=True)
+    eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))
+    pc = synthetic.critic_params(F_, 8 * S, 2)
+    eng.C.load_state_dict(pc)
+    coarse, fine = synthetic.tiles(B, cin, S)
+    xc = nchw_to_nhwc_padded(torch.from_numpy(coarse), eng.G.cin_p, ops.tdtype)
+    xf = nchw_to_nhwc_padded(torch.from_numpy(fine), eng.G.np_p, ops.tdtype)
+    alpha = torch.from_numpy(synthetic.alpha(B, 0))
+    eng.critic_iteration(xc, xf, alpha, apply_update=False, save_g=True)       # clean: no exception
+    eng.generator_iteration(xc, xf, apply_update=False, reuse_fake=True)
+    bad = {k: v.copy() for k, v in pc.items()}
+    bad["features.6.weight"][3, 2, 1, 1] = float("nan")
+    eng.C.load_state_dict(bad)
+    with pytest.raises(FloatingPointError, match="critic iteration") as ei:
+        eng.critic_iteration(xc, xf, alpha, apply_update=False)
+    assert "loss scalars" in str(ei.value) or "features.6.weight" in str(ei.value)
+    eng.C.load_state_dict(pc)
+    xf_bad = xf.clone(); xf_bad[0, 3, 3, 0] = float("inf")
+    with pytest.raises(FloatingPointError):
+        eng.generator_iteration(xc, xf_bad, apply_update=False)

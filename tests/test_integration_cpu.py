@@ -126,7 +126,63 @@ def test_epoch_loop_checkpoints_both_networks(monkeypatch, tmp_path):
 
 def test_ragged_last_batch_rebinds_the_engine(monkeypatch):
     """A DataLoader's ragged last batch (the reference's own _gp cannot take it: wasserstein.py:110 reshapes with hp.batch_size):
-    the mirror re-creates its shape-bound engine for the new batch size and carries the CURRENT parameters over."""
+    the mirror re-creates its shape-bound engine for the new batch size and carries the parameters AND both Adam states over, so
+    the two steps equal two steps of ONE continuously running optimizer (stage.py:63-64) -- checked against the oracle run the same
+    way, and told apart from an optimizer whose moments restart at the re-bind."""
+    from downgan_amd import backend, synthetic
+    from downgan_amd.GAN import losses
+    from downgan_amd.GAN.dataloader import NetCDFSR
+    from downgan_amd.GAN.wasserstein import WassersteinGAN
+    from downgan_amd.networks.critic import Critic
+    from downgan_amd.networks.generator import Generator
+    from oracle import ref_step
+    from oracle.emu_ops import EmuOps
+    import downgan_amd.config.hyperparams as hp
+    monkeypatch.setattr(backend, "make_ops", lambda dtype, device: EmuOps("f32"))
+    monkeypatch.setattr(losses, "_ops", {})
+    monkeypatch.setattr(hp, "batch_size", 2)
+    torch.set_num_threads(4)
+    coarse, fine = synthetic.tiles(3, 2, 16, seed=6)
+    tc, tf = torch.from_numpy(coarse), torch.from_numpy(fine)
+    G, C = Generator(16, 128, 2, 2, num_res_blocks=1), Critic(16, 128, 2)
+    sd0 = C.state_dict()
+    tr = WassersteinGAN(G, C)
+    tr.log_metrics = False
+    alphas = [torch.from_numpy(synthetic.alpha(2, 0)), torch.from_numpy(synthetic.alpha(1, 1))]
+    it = iter(alphas)
+    monkeypatch.setattr(tr, "_alpha", lambda e, a: next(it))
+    dl = torch.utils.data.DataLoader(NetCDFSR(tc, tf), batch_size=2)
+    (log,) = tr.train(dl, None, epochs=1)
+    assert len(log) == 2 and tr._engine.B == 1 and tr.num_steps == 2
+    assert tr._engine.C.P.t == 2 and tr._engine.G.P.t == 1            # the step counts travelled with the moments
+    import math
+    assert math.isfinite(log[0]["critic_loss"]) and math.isfinite(log[1]["critic_loss"])
+    sd1 = C.state_dict()
+    moved = max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0)
+    assert 1.5 * hp.lr < moved <= 2.0 * hp.lr * 1.01, moved        # Adam moves an entry by at most lr per step: > 1.5 lr needs both steps
+
+    def oracle(reset):
+        pg = {k: torch.from_numpy(v) for k, v in synthetic.generator_params(16, 2, 2, 1).items()}
+        pc = {k: torch.from_numpy(v) for k, v in synthetic.critic_params(16, 128, 2).items()}
+        orc = ref_step.OracleTrainer(pg, pc, ref_step.HP(batch_size=2), num_res_blocks=1)
+        r0 = orc.train_step(tc[:2], tf[:2], alphas[0])
+        orc.hp.batch_size = 1                                      # wasserstein.py:110 reads the global batch size
+        if reset:
+            orc.C_opt = ref_step.Adam(orc.PC, orc.hp)
+        r1 = orc.train_step(tc[2:], tf[2:], alphas[1])
+        return r0, r1, {k: v.detach() for k, v in orc.PC.items()}
+    r0, r1, cont = oracle(False)
+    _, _, restarted = oracle(True)
+    for k in ("critic_loss", "c_real_mean", "gp_ret"):
+        assert abs(log[0][k] - r0[k]) <= 1e-4 * max(abs(r0[k]), 1e-3) and abs(log[1][k] - r1[k]) <= 1e-4 * max(abs(r1[k]), 1e-3), (k, log[1][k], r1[k])
+    d_cont = sum(float((sd1[k] - cont[k]).abs().sum()) for k in cont)
+    d_restart = sum(float((sd1[k] - restarted[k]).abs().sum()) for k in cont)
+    assert d_cont < 0.1 * d_restart, (d_cont, d_restart)
+
+
+def test_test_loader_with_another_batch_size_is_evaluated(monkeypatch):
+    """The epoch's test pass (wasserstein.py:157-170) evaluates EVERY test batch, also when the test loader's batch size differs
+    from the train loader's or its last batch is ragged -- none is dropped silently; an empty test loader raises."""
     from downgan_amd import backend, synthetic
     from downgan_amd.GAN import losses
     from downgan_amd.GAN.dataloader import NetCDFSR
@@ -139,16 +195,14 @@ def test_ragged_last_batch_rebinds_the_engine(monkeypatch):
     monkeypatch.setattr(losses, "_ops", {})
     monkeypatch.setattr(hp, "batch_size", 2)
     torch.set_num_threads(4)
-    coarse, fine = synthetic.tiles(3, 2, 16, seed=6)
-    G, C = Generator(16, 128, 2, 2, num_res_blocks=1), Critic(16, 128, 2)
-    tr = WassersteinGAN(G, C)
-    tr.log_metrics = False
-    dl = torch.utils.data.DataLoader(NetCDFSR(torch.from_numpy(coarse), torch.from_numpy(fine)), batch_size=2)
-    (log,) = tr.train(dl, None, epochs=1)
-    assert len(log) == 2 and tr._engine.B == 1 and tr.num_steps == 2
-    import math
-    assert math.isfinite(log[0]["critic_loss"]) and math.isfinite(log[1]["critic_loss"])
-    # two critic updates reached the mirror's parameters: both engines (B = 2, then B = 1) worked on the same network
-    sd0, sd1 = Critic(16, 128, 2).state_dict(), C.state_dict()
-    moved = max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0)
-    assert 1.5 * hp.lr < moved <= 2.0 * hp.lr * 1.01, moved        # Adam moves an entry by at most lr per step: > 1.5 lr needs both steps
+    coarse, fine = synthetic.tiles(5, 2, 16, seed=8)
+    tc, tf = torch.from_numpy(coarse), torch.from_numpy(fine)
+    tr = WassersteinGAN(Generator(16, 128, 2, 2, num_res_blocks=1), Critic(16, 128, 2))
+    train = torch.utils.data.DataLoader(NetCDFSR(tc[:2], tf[:2]), batch_size=2)
+    test = torch.utils.data.DataLoader(NetCDFSR(tc[2:], tf[2:]), batch_size=2)     # batches of 2 and 1
+    tr.train(train, test, epochs=1)
+    (ep,) = tr.metrics_log
+    assert ep["test_batches"] == 2 and set(ep["test"]) >= {"MAE", "MSE", "Wass"}
+    assert tr._engine.C.P.t == 1                                                   # the test pass re-bound the engine, the optimizer state survived
+    with pytest.raises(ValueError):
+        tr.train(train, torch.utils.data.DataLoader(NetCDFSR(tc[:0], tf[:0]), batch_size=2), epochs=1)
