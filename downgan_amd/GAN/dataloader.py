@@ -81,7 +81,10 @@ class ResidentLoader:
     def from_fields(cls, coarse_fields: dict, fine_fields: dict, coarse_order, fine_order, batch_size, stats=None, **kw):
         """Raw per-variable records (``{name: [time, lat, lon] fp32}``, e.g. ERA-Interim covariates and WRF predictands) ->
         standardised resident stores (GAN/preprocess.py: gen_experiment_datasets.py:195-233 + stage.py:28-31 in two GPU
-        passes) -> loader.  ``stats`` ({"coarse": ..., "fine": ...}) re-uses the TRAIN statistics for a test split."""
+        passes) -> loader.  ``stats`` ({"coarse": ..., "fine": ...}): statistics to standardise with instead of this record's own.
+        The reference standardises each variable over its WHOLE record before the train / test split
+        (gen_experiment_datasets.py:241-250): to reproduce it pass ``preprocess.whole_record_stats(ops, train, test)`` for BOTH
+        splits (statistics of the train split alone are a different, leakage-free convention)."""
         from . import preprocess
         ops = kw.pop("ops", None) or backend.make_ops(kw.get("dtype", "bf16"), kw.get("device", "cuda:0"))
         chunk = kw.get("stage_chunk", 64)

@@ -24,7 +24,12 @@ def _chunks(t, chunk):
 
 
 def field_stats(ops, fields: dict, exempt=EXEMPT, chunk=64):
-    """{name: (mean, std)} over each field's whole record (NaNs skipped, population std); exempt fields -> (0.0, 1.0)."""
+    """{name: (mean, std)} over each field's whole record (NaNs skipped, population std); exempt fields -> (0.0, 1.0).
+
+    To reproduce the reference, ``fields`` must hold each variable's WHOLE record: gen_experiment_datasets.py:241-250 standardises
+    before the year-based train / test split, so both splits share statistics taken over train + test together
+    (``whole_record_stats`` below takes the two splits and does that).  A field without a finite value raises; a constant field
+    (std 0) raises too -- the reference would divide by zero and fill it with NaN / Inf."""
     stats = {}
     acc = torch.zeros(3, dtype=torch.float64, device=ops.device)
     for name, t in fields.items():
@@ -35,10 +40,23 @@ def field_stats(ops, fields: dict, exempt=EXEMPT, chunk=64):
         for _, part in _chunks(t, chunk):
             ops.moments(part.to(ops.device).contiguous(), acc)
         s, ss, n = acc.cpu().tolist()
+        if n == 0:
+            raise ValueError(f"field '{name}' has no finite value: its mean / std are undefined")
         mean = s / n
         var = max(ss / n - mean * mean, 0.0)
+        if var == 0.0:
+            raise ValueError(f"field '{name}' is constant ({mean}): (x - mean) / std is undefined -- list it in `exempt` (as the "
+                             "reference does for the binary land_sea_mask) or drop it")
         stats[name] = (mean, var ** 0.5)
     return stats
+
+
+def whole_record_stats(ops, train_fields: dict, test_fields: dict, exempt=EXEMPT, chunk=64):
+    """Statistics over train + test together, as the reference computes them (it standardises each variable's whole record and
+    only then splits by year, gen_experiment_datasets.py:241-250): pass the result as ``stats=`` when staging EITHER split."""
+    both = {k: torch.cat([torch.as_tensor(train_fields[k], dtype=torch.float32), torch.as_tensor(test_fields[k], dtype=torch.float32)], 0)
+            for k in train_fields}
+    return field_stats(ops, both, exempt, chunk)
 
 
 def stage_standardized(ops, fields: dict, order, stats=None, exempt=EXEMPT, chunk=64):

@@ -76,3 +76,42 @@ def test_two_ranks_on_one_gpu_rehearsal():
     with tempfile.TemporaryDirectory() as d:
         ranks = _launch("gloo", "f32", d)
     _compare(ranks, _single("f32"))
+
+
+def _bench(*args):
+    """`python bench.py ...` as typed, as a child process (the parent test process has initialised the GPU: never exec from it)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]               # rank 0 prints ONE JSON line, whatever the rank count
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_rehearsal_line():
+    """bench.py's own rank launcher (`--gpus 2` typed bare: the parent starts two fresh rank processes before touching the GPU),
+    here as the one-GPU rehearsal: one JSON line, marked as a rehearsal, both ranks reported, finite losses."""
+    import math
+    d = _bench("--gpus", "2", "--rehearse-on-one-gpu", "--workload", "mid", "--steps", "5", "--warmup", "1", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
+    assert d["rehearsal"] is True and "REHEARSAL" in d["config"]["exchange"]
+    assert d["steps"] == 5 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert [r["rank"] for r in d["ranks_seen"]] == [0, 1] and all(r["device"] == "cuda:0" for r in d["ranks_seen"])
+    assert len({r["pid"] for r in d["ranks_seen"]}) == 2
+    assert all(math.isfinite(v) for v in d["losses"].values()) and {"critic_loss", "gp_ret", "g_loss"} <= set(d["losses"])
+    assert "fp8" not in d and "cpu_baseline" not in d       # single-GPU extras only
+
+
+def test_bench_default_line_carries_fp8_and_event_free_numbers():
+    """The default single-GPU command (small workload here) also reports the fp8 mode (BASELINE configs[4]) and a short region
+    without per-launch events, and is not marked as a rehearsal."""
+    d = _bench("--workload", "mid", "--steps", "5", "--warmup", "1", "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["rehearsal"] is False and d["dtype"] == "bf16" and d["ranks_seen"][0]["device"] == "cuda:0"
+    assert d["roofline"]["frac"] > 0 and d["critic_conv_stack"]["mfma_frac"] > 0
+    assert d["without_kernel_events"]["steps"] == 5 and d["without_kernel_events"]["ms_per_step"] > 0
+    f8 = d["fp8"]
+    assert f8["steps"] == 5 and f8["value"] > 0 and f8["roofline"]["peak"] == 5000.0 and f8["roofline"]["launches"] > 0
+    import math
+    assert all(math.isfinite(v) for v in f8["losses"].values())

@@ -60,3 +60,26 @@ def test_native_host_logic_on_emulated_ops():
     # a test split re-uses the train statistics
     ld2 = ResidentLoader.from_fields(f, fine, ORDER, ["u", "v"], batch_size=2, shuffle=False, ops=ops, stats=ld.stats)
     assert torch.equal(ld2.store_c.nan_to_num(), ld.store_c.nan_to_num())
+
+
+def test_degenerate_fields_raise_and_whole_record_statistics():
+    """A constant non-exempt field or a field without a finite value raises instead of dividing by zero (the reference would write
+    NaN / Inf); `whole_record_stats` = statistics over train + test together, the reference's order of operations
+    (gen_experiment_datasets.py:241-250: standardise, then split)."""
+    import pytest
+    from downgan_amd.GAN import preprocess as pp
+    from oracle.emu_ops import EmuOps
+    ops = EmuOps("f32")
+    f = raw_fields()
+    const = dict(f, u10=np.full_like(f["u10"], 3.5))
+    with pytest.raises(ValueError, match="constant"):
+        pp.field_stats(ops, const)
+    nan = dict(f, t2=np.full_like(f["t2"], np.nan))
+    with pytest.raises(ValueError, match="no finite value"):
+        pp.field_stats(ops, nan)
+    train = {k: v[:6] for k, v in f.items()}
+    test = {k: v[6:] for k, v in f.items()}
+    both = pp.whole_record_stats(ops, train, test, chunk=4)
+    whole = pp.field_stats(ops, f)
+    for k in f:
+        assert abs(both[k][0] - whole[k][0]) <= 1e-9 * abs(whole[k][0]) + 1e-12 and abs(both[k][1] - whole[k][1]) <= 1e-9 * whole[k][1] + 1e-12
