@@ -1,0 +1,314 @@
+// The halo-patch conv kernel (forward of both strides, every data gradient of the wide layers): the dominant kernel of the step.
+#include "gg_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Halo path (unit-stride gathers: stride-1 forward, every data gradient; stride-2 forward through parity planes).  One
+// workgroup = a 16x16 tile of the GEMM-row grid of ONE image x 128 output channels.  The 9 taps of a 3x3 stencil read
+// overlapping source pixels, so instead of staging a [pixels][K-slice] operand per tap (9x the bytes) the workgroup keeps
+// the (16+2)x(16+2) source PATCH of the current channel block in LDS and every tap reads its fragments from the patch at a
+// shifted row; only the weights stream per tap-step.
+#ifdef DG_STAMP
+// diagnostic build only (make stamp): per-wave cycle sums of the segments of a tap-step, blocks 0/1
+__device__ unsigned long long g_stamps[2 * 8 * 8];
+extern "C" int dg_debug_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
+}
+#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(v) do { } while (0)
+#endif
+// S2 = stride-2 forward on the same machinery.  out(y,x) = sum_{r,s} in(2y+r-1, 2x+s-1) w(r,s): split the input into its four
+// parity planes (py,px) = (row & 1, col & 1) of 2x2 blocks; tap r reads plane py = (r != 1) at block offset (r == 0 ? -1 : 0),
+// so every tap is a UNIT-stride shift in block coordinates.  The K loop runs over (plane, channel block) pairs; the patch
+// of a pair is the 17x17 blocks of that plane (gathered with stride 2 straight from the NHWC tensor), and
+// the pair's taps are the 1 / 2 / 2 / 4 taps that read the plane (a.tap_* are grouped by plane by gg_regroup_taps_by_plane).
+bool gg_regroup_taps_by_plane(GGArgs& a) {
+  if (a.ntaps != 9) return false;
+  unsigned codes[9], out[9];
+  bool seen[3][3] = {};
+  for (int t = 0; t < 9; ++t) {
+    codes[t] = t < 8 ? (unsigned)((a.tap_lo >> (8 * t)) & 0xffull) : (a.tap_hi & 0xffu);
+    const int dy = (int)(codes[t] & 3u) - 1, dx = (int)((codes[t] >> 2) & 3u) - 1;
+    if (dy < -1 || dy > 1 || dx < -1 || dx > 1 || seen[dy + 1][dx + 1]) return false;
+    seen[dy + 1][dx + 1] = true;
+  }
+  int n = 0;
+  for (int plane = 0; plane < 4; ++plane)
+    for (int t = 0; t < 9; ++t) {
+      const int dy = (int)(codes[t] & 3u) - 1, dx = (int)((codes[t] >> 2) & 3u) - 1;
+      if ((dy != 0) * 2 + (dx != 0) != plane) continue;
+      const unsigned by = dy == -1 ? 0u : 1u, bx = dx == -1 ? 0u : 1u;      // block offset + 1
+      out[n++] = by | (bx << 2) | (codes[t] & 0xf0u);
+    }
+  a.tap_lo = 0; a.tap_hi = 0;
+  for (int t = 0; t < 9; ++t) {
+    if (t < 8) a.tap_lo |= (unsigned long long)out[t] << (8 * t); else a.tap_hi = out[t];
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Four-wave halo kernel, TWO workgroups per CU.  Tile: 16x16 pixels x 128 output channels, 64-channel K-steps, so patch (324 x 144 B) + two 16-KB weight slots = 78 KB and a second, independent workgroup shares
+// the CU: its tap-step loop runs while this one sits in its prologue (exposed patch latency) or in its store-bound
+// epilogue (then ~14k cycles per tile; 7-11k since the 16-byte, flag-specialised epilogue), which is where 9..18-step tiles
+// lose 30-50 % of their time; and
+// the two waves of a SIMD now belong to different workgroups (no shared barrier, no lock-step).  Each wave owns 4 tile
+// rows x all 128 channels (8 x 4 accumulator fragments, 3 LDS fragment reads per 8 MFMAs instead of 4).
+// One barrier per step, at its top:  BARRIER | DMA W[s+2] -> slot s&1 | mma(k0) | read k0 of s+1 | mma(k1) | read k1 of s+1.
+// S2: stride-2 forward over the four parity planes of the input (above): K loop over (plane, channel block)
+// pairs with 1 / 2 / 2 / 4 taps, the plane's patch gathered with stride 2.
+// PS: pixel-shuffled source (data gradient of an up-sampling conv): virtual pixel (y, x), channel quarter q = stored pixel
+// (2y + (q >> 1), 2x + (q & 1)); a 64-channel block lies inside one quarter, so its patch is a stride-2 gather like S2's.
+// NW = 8: the same kernel with EIGHT waves and a 16x16-pixel x 256-channel tile (waves 0-3 the first 128 channels, waves 4-7
+// the second), one workgroup per CU.  Both channel halves read ONE patch, so the patch bytes per flop halve -- which is what
+// bounds the stride-2 forward (a stride-2 tile reads 4x the input pixels of a stride-1 tile: 227 flop per patch byte at 128
+// channels, and the per-CU global->LDS path sustains only ~10-12 B/clk) -- at the price of the second, independent workgroup.
+template <typename T, bool S2, bool PS = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+  constexpr int NT = 64 * NW, RPP = NT / 8;                              // threads; patch rows staged per pass
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
+  constexpr int BC = 32 * NW, KC = 8;                                    // 8 chunks per row: 64 bf16 / 32 fp32 channels
+  constexpr int PITCH = KC * 16 + 16;                                    // 144 B patch rows
+  constexpr int WROW = KC * 16;                                          // 128 B weight rows, chunk c of row r at c ^ ((r >> 1) & 7)
+  constexpr int NPL = (PROWS * KC + NT - 1) / NT;                        // 11 (6) patch chunks per thread
+  constexpr int NWL = BC * KC / NT;                                      // 4 weight pieces per wave and step
+  extern __shared__ __attribute__((aligned(16))) char dsm4w[];
+  char* const s_patch = dsm4w;                    // [PROWS][PITCH]
+  char* const s_w = dsm4w + PROWS * PITCH;        // [2][BC][WROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const int tile_c = tile % a.nct;
+  unsigned rest = tile / a.nct;
+  const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
+  const int ty0 = (rest % tiles_y) * TH;
+  const int img = rest / tiles_y;
+  const int c0 = tile_c * BC;
+  const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0, RPP)
+  const int wq = wave & 3, wh = wave >> 2;        // tile rows 4*wq.., channel half wh (0 unless NW = 8)
+  const int sy_base = S2 ? (ty0 > 0 ? 2 * (ty0 - 1) : 0) : (ty0 - 1 > 0 ? ty0 - 1 : 0);
+  const char* Xb = PS ? reinterpret_cast<const char*>(a.x) + ((long long)img * 2 * a.Hs + 2 * sy_base) * (2 * a.Ws) * a.ldx * ES
+                      : reinterpret_cast<const char*>(a.x) + ((long long)img * a.Hs + sy_base) * a.Ws * a.ldx * ES;
+  const char* Wb = reinterpret_cast<const char*>(a.w) + (long long)c0 * a.ldw * ES;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ncbr = a.cch / KC;                    // real channel blocks
+  const int ncb = S2 ? 4 * ncbr : ncbr;           // (plane, channel block) pairs, plane-major
+  const int nsteps = ncbr * a.ntaps;
+  auto plane_of = [&](int vcb) { return S2 ? (int)(vcb >= ncbr) + (int)(vcb >= 2 * ncbr) + (int)(vcb >= 3 * ncbr) : 0; };
+  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : a.ntaps; };
+
+  unsigned woff[NWL];                             // DMA piece i of this wave: rows wave*32 + 8i .. +7, lane = (row, physical chunk)
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    int row = wave * 32 + i * 8 + (lane >> 3);
+    const int logical = (lane & 7) ^ ((row >> 1) & 7);
+    row = perm64(row);                              // LDS row holds output channel c0 + perm64(row)
+    if (c0 + row >= a.Nout) row = a.Nout - 1 - c0;
+    woff[i] = (unsigned)((long long)row * a.ldw * ES) + logical * 16;
+  }
+  auto tap_code = [&](int vcb, int tap) {
+    const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap;
+    return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
+  };
+  u32x4_t rp[NPL];
+  auto load_patch = [&](int vcb) {
+    const int plane = plane_of(vcb), cb = vcb - plane * ncbr;
+    const int ppy = plane >> 1, ppx = plane & 1;
+    const int psq = PS ? (cb * KC) / a.cps_src_chunks : 0;                 // channel quarter of this block
+    const int psy = psq >> 1, psx = psq & 1;
+    const long long cboff = PS ? (long long)(cb * KC - psq * a.cps_src_chunks) * EPC * ES : (long long)cb * KC * EPC * ES;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + cboff), 0, (int)DG_OOB_OFF, 0x00020000);
+    int r0v = r0;
+    asm volatile("" : "+v"(r0v));
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0v + RPP * i;
+      const int py = pr / PW, px = pr - py * PW;
+      const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
+      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+      const unsigned off = !ok ? DG_OOB_OFF
+                           : PS ? (unsigned)(((2 * (sy - sy_base) + psy) * (2 * a.Ws) + 2 * sx + psx) * a.ldx * ES) + cc * 16
+                                : (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16;
+      rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  char* const st_base = s_patch + r0 * PITCH + cc * 16;
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pr = r0 + RPP * i;
+      if (pr < PROWS) *reinterpret_cast<uint4*>(st_base + i * RPP * PITCH) = __builtin_bit_cast(uint4, rp[i]);
+    }
+  };
+  typedef int i32x4h_t __attribute__((ext_vector_type(4)));
+  i32x4h_t w_rs;
+  int w_dst0 = 0;
+  auto dma_setup = [&](int vcb, int tap, int slot) {
+    const unsigned code = tap_code(vcb, tap);
+    const long long wo = (long long)(code >> 4) * a.Cred + (vcb - plane_of(vcb) * ncbr) * KC * EPC;
+    const unsigned long long wbase = (unsigned long long)(Wb + wo * ES);
+    w_rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wbase);
+    w_rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(wbase >> 32) & 0xffff);
+    w_rs[2] = (int)DG_OOB_OFF;
+    w_rs[3] = 0x00020000;
+    w_dst0 = __builtin_amdgcn_readfirstlane(
+        (int)(unsigned long long)((__attribute__((address_space(3))) char*)(s_w + slot * (BC * WROW) + (wave * 32) * WROW)));
+  };
+  auto dma_piece = [&](int i) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(w_dst0 + i * 8 * WROW), "v"(woff[i]), "s"(w_rs) : "memory");
+  };
+  auto dma_w = [&](int cb, int tap, int slot) {
+    dma_setup(cb, tap, slot);
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) dma_piece(i);
+  };
+  auto barrier_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
+  auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPL) : "memory"); __syncthreads(); };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const char* fa_k[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) fa_k[kk] = s_w + (wh * 128 + l15) * WROW + (((kk * 4 + g) ^ ((l15 >> 1) & 7)) * 16);
+  const char* const fb_lane = s_patch + l15 * PITCH + g * 16;
+  auto read_frags = [&](uint4 (&fa)[8], uint4 (&fb)[4], int pa, const char* pb, int kk) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] = *reinterpret_cast<const uint4*>(fa_k[kk] + pa + j * 16 * WROW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + kk * 64);
+  };
+  auto mma_rows = [&](const uint4 (&fa)[8], const uint4 (&fb)[4], int j0) {     // two weight fragments x four pixel rows
+#pragma unroll
+    for (int j = j0; j < j0 + 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Mma<T>::run(fa[j], fb[i], acc[j][i]);
+  };
+  auto adv = [&](int& c_, int& t_) { if (++t_ == ntaps_of(c_)) { t_ = 0; ++c_; } };
+  auto patch_ptr = [&](int vcb_, int tap_) -> const char* {
+    const unsigned code = tap_code(vcb_, tap_);
+    const int dy = (int)(code & 3u) - 1, dx = (int)((code >> 2) & 3u) - 1;
+    return fb_lane + ((wq * 4 + 1 + dy) * PW + 1 + dx) * PITCH;
+  };
+
+#ifdef DG_STAMP
+  unsigned long long tK0 = 0, tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, sAB = 0, sBC = 0, sCD = 0, sDE = 0, tL0 = 0;
+  STAMP(tK0);
+#endif
+  load_patch(0);
+  int cb = 0, tap = 0, cbw = 0, tapw = 0;
+  dma_w(0, 0, 0);
+  adv(cbw, tapw);
+  if (nsteps > 1) dma_w(cbw, tapw, 1);
+  adv(cbw, tapw);                    // -> W[2]
+  store_patch();
+  barrier_all();
+  // ONE fragment set (accumulators 128 + fragments 48 + patch staging 44 registers): a wave waits for its LDS reads in
+  // the open, which is what the second workgroup on the CU is there to cover.
+  uint4 fa[8], fb[4];
+  const char* pb = patch_ptr(0, 0);
+  int pa = 0;
+  read_frags(fa, fb, pa, pb, 0);
+  STAMP(tL0);
+  for (int s = 0; s < nsteps; ++s) {
+    STAMP(tA);
+    const bool more = s + 1 < nsteps;
+    int ntap = tap + 1, ncbn = cb;
+    const int ntaps_cb = ntaps_of(cb);
+    if (ntap == ntaps_cb) { ntap = 0; ncbn = cb + 1; }
+    const bool swap = ntap == 0 && more;
+    const bool patch_now = cb + 1 < ncb && (ntaps_cb == 1 || tap == 0);     // fetch the next block's patch during its predecessor's first step
+    const bool fetch = s + 2 < nsteps;
+    // k-block 0 (fragments read at the end of the previous step), then k-block 1: after it every wave has read all it
+    // needs of this step, so the barrier below frees slot s&1 (and, at a block end, the patch); W[s+1] has landed by then
+    // k-block 0, and the weight fragments of k-block 1 re-read row pair by row pair right behind the MFMAs that consumed their
+    // k-block-0 contents (that latency hides under the remaining rows; only the four pixel fragments are read in the open at
+    // the end): +0.5-1.5 % per launch against reading all twelve fragments after the block (the chip gives about half of a
+    // cycle saving back as clock).  The asm fences keep each read in its slot and each MFMA pair in front of it.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mma_rows(fa, fb, 2 * q);
+      asm volatile("" : "+v"(acc[2 * q][0]), "+v"(acc[2 * q][1]), "+v"(acc[2 * q][2]), "+v"(acc[2 * q][3]),
+                        "+v"(acc[2 * q + 1][0]), "+v"(acc[2 * q + 1][1]), "+v"(acc[2 * q + 1][2]), "+v"(acc[2 * q + 1][3]) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      fa[2 * q] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q) * 16 * WROW);
+      fa[2 * q + 1] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q + 1) * 16 * WROW);
+      asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    if (patch_now) load_patch(cb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(tB);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mma_rows(fa, fb, 2 * q);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(tC);
+    if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
+    STAMP(tD);
+    pa = ((s + 1) & 1) * (BC * WROW);
+    pb = patch_ptr(ncbn < ncb ? ncbn : 0, ntap);
+    if (swap) {                      // channel-block boundary: the single-buffered patch is rewritten, then published
+      store_patch();
+      barrier_all();
+    }
+    // next step's first fragments go out before the DMA pieces: the ~700 cycles a wave spends issuing those then cover
+    // the LDS read latency instead of preceding it
+    if (more) read_frags(fa, fb, pa, pb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (fetch) { dma_setup(cbw, tapw, s & 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma_piece(q);
+    }
+    adv(cbw, tapw);
+    __builtin_amdgcn_sched_barrier(0);
+    tap = ntap; cb = ncbn;
+    STAMP(tE);
+#ifdef DG_STAMP
+    sAB += tB - tA; sBC += tC - tB; sCD += tD - tC; sDE += tE - tD;
+#endif
+  }
+#ifdef DG_STAMP
+  unsigned long long tL1, tX;
+  STAMP(tL1);
+#endif
+  halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
+#ifdef DG_STAMP
+  STAMP(tX);
+  if (blockIdx.x < 2 && lane == 0) {
+    unsigned long long* o = g_stamps + (blockIdx.x * 8 + wave) * 8;
+    o[0] = sAB; o[1] = sBC; o[2] = sCD; o[3] = sDE; o[4] = (unsigned long long)nsteps; o[5] = tL1 - tL0; o[6] = tX - tL1; o[7] = tL0 - tK0;
+  }
+#endif
+}
+
+template <typename T, bool S2, bool PS = false, int NW = 4>
+static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
+  constexpr int BC = 32 * NW;
+  constexpr int LDS_BYTES = 324 * 144 + 2 * BC * 128;
+  DG_SET_MAX_LDS_ONCE((&gg_halo4w_kernel<T, S2, PS, NW>), LDS_BYTES);
+  const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
+  a.nct = (unsigned)((a.Nout + BC - 1) / BC);
+  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  g_last_kinds |= 8;
+  hipLaunchKernelGGL((gg_halo4w_kernel<T, S2, PS, NW>), dim3(a.nwg), dim3(64 * NW), LDS_BYTES, st, a, tiles_x, tiles_y);
+  return dg_check_launch();
+}
+
+int gg_launch_halo(GGArgs& a, int dtype, int N, bool s2, bool ps, int nw, hipStream_t st) {
+  if (dtype == DG_F32) {
+    if (ps) return gg_launch_halo4w<float, false, true>(a, N, st);
+    return s2 ? gg_launch_halo4w<float, true>(a, N, st) : gg_launch_halo4w<float, false>(a, N, st);
+  }
+  if (ps) return gg_launch_halo4w<bf16_t, false, true>(a, N, st);
+  if (s2) return nw == 8 ? gg_launch_halo4w<bf16_t, true, false, 8>(a, N, st) : gg_launch_halo4w<bf16_t, true>(a, N, st);
+  return gg_launch_halo4w<bf16_t, false>(a, N, st);
+}

@@ -1,0 +1,245 @@
+// Host side of the conv family: lowering of a 3x3 conv layer to gather-GEMM descriptors (dg_conv3x3_plan, no GPU needed),
+// the choice of kernel for a descriptor, and the C ABI entry points.
+#include "gg_common.h"
+
+thread_local int g_last_kinds = 0;
+
+// ------------------------------------------------------------------------------------ host side
+static int gg_validate(const dg_gg_desc* d, bool f8 = false, bool compact_src = false) {
+  if (d->dtype != DG_F32 && d->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  const int epc = f8 ? 16 : d->dtype == DG_F32 ? 4 : 8;
+  if (d->N <= 0 || d->Hs <= 0 || d->Ws <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->Hd <= 0 || d->Wd <= 0) return DG_ERR_BAD_SHAPE;
+  if (d->Cred <= 0 || d->Cred % 8 || d->Nout <= 0 || d->Nout % 16) return DG_ERR_BAD_SHAPE;
+  if (d->ntaps < 1 || d->ntaps > 9) return DG_ERR_BAD_SHAPE;
+  // compact_src: the im2col kernel gathers single (channel 0, channel 1) pairs, so its source may be a tensor that stores the
+  // real channels only (pixel stride 2: one dword in bf16) instead of the 16-channel padded form -- 8x fewer cache lines per gather
+  if ((compact_src ? d->lds % 2 || d->lds < 2 : d->lds % epc) || d->ldd % 4 || d->ldw % epc) return DG_ERR_BAD_SHAPE;
+  for (int t = 0; t < d->ntaps; ++t) {
+    if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1) return DG_ERR_BAD_ARG;
+    if (d->tap_w[t] < 0 || d->tap_w[t] > 8) return DG_ERR_BAD_ARG;
+  }
+  if (d->src_ps && ((d->Cred / 4) % 8)) return DG_ERR_BAD_SHAPE;
+  if (d->dst_ps && ((d->Nout / 4) % 16)) return DG_ERR_BAD_SHAPE;
+  if ((long long)d->N * d->Hg * d->Wg >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
+  // every destination pixel must be inside the destination tensor
+  if (d->dst_ps) {
+    if (2 * d->Hg > d->Hd || 2 * d->Wg > d->Wd) return DG_ERR_BAD_SHAPE;
+  } else {
+    if ((d->Hg - 1) * d->dy_mul + d->dy_off >= d->Hd || (d->Wg - 1) * d->dx_mul + d->dx_off >= d->Wd) return DG_ERR_BAD_SHAPE;
+    if (d->dy_off < 0 || d->dx_off < 0 || d->dy_mul < 1 || d->dx_mul < 1) return DG_ERR_BAD_SHAPE;
+  }
+  return DG_OK;
+}
+
+// Kernel choice for one descriptor (bf16 / fp32).
+static int gg_launch(GGArgs& a, int dtype, int N, hipStream_t st) {
+  // halo kernel: the patch is sized for tap shifts in [-1, 1] around a unit-stride grid (stride-1 forward, all data gradients;
+  // also single-tap launches: the 1-tap parity class of a stride-2 data gradient)
+  if (a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 && a.Hs == a.Hg && a.Ws == a.Wg)
+    return gg_launch_halo(a, dtype, N, false, false, 4, st);
+  // pixel-shuffled sources (data gradients of the up-sampling convs) whose channel quarters hold whole 64-channel blocks
+  if (a.sy_mul == 1 && a.sx_mul == 1 && a.src_ps && a.cps_src_chunks % 8 == 0 && a.cch % 8 == 0 && a.Nout > 64 &&
+      a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 && a.Hs == a.Hg && a.Ws == a.Wg)
+    return gg_launch_halo(a, dtype, N, false, true, 4, st);
+  // stride-2 forward through the four parity planes of the input
+  if (a.sy_mul == 2 && a.sx_mul == 2 && !a.src_ps && a.cch % 16 == 0 && a.Nout > 64 && a.Hg >= 8 &&
+      a.Wg >= 8 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1)
+  {
+    GGArgs b = a;
+    if (gg_regroup_taps_by_plane(b)) {
+      // >= 256 output channels (bf16): eight waves share one parity-plane patch between two 128-channel halves
+      static const bool no8w = getenv("DG_GG_NO8W") != nullptr;
+      return gg_launch_halo(b, dtype, N, true, false, (dtype == DG_BF16 && !no8w && b.Nout % 256 == 0) ? 8 : 4, st);
+    }
+  }
+  if (a.Nout <= 16 && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && !a.dst_ps && a.cch % 8 == 0 && a.Hg >= 8 &&
+      a.Wg >= 8 && a.ntaps >= 2 && a.Hs == a.Hg && a.Ws == a.Wg && !a.mask_bits && !a.out_bits)
+    return gg_launch_halo16(a, dtype, N, st);
+  return gg_launch_rows(a, dtype, st);
+}
+
+// fp8 launches: only the shapes the four-wave halo kernel takes (the critic's wide layers); everything else is refused
+static int gg_launch_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st) {
+  if (a.cch % 8 || a.Nout <= 64 || a.Hg < 8 || a.Wg < 8 || a.src_ps || a.dst_ps) return DG_ERR_BAD_SHAPE;
+  if (a.sy_mul == 1 && a.sx_mul == 1 && a.Hs == a.Hg && a.Ws == a.Wg) return gg_launch_halo_f8(a, f, N, false, 4, st);
+  if (a.sy_mul == 2 && a.sx_mul == 2 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1) {
+    GGArgs b = a;
+    if (gg_regroup_taps_by_plane(b)) {
+      static const bool no8w = getenv("DG_GG_NO8W") != nullptr;
+      return gg_launch_halo_f8(b, f, N, true, (!no8w && b.Nout % 256 == 0) ? 8 : 4, st);
+    }
+  }
+  return DG_ERR_BAD_SHAPE;
+}
+static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w, void* y, void* stream,
+                            bool im2col_small, const dg_f8_operands* f8 = nullptr) {
+  if (!d || !x || !w || !y) return DG_ERR_BAD_ARG;
+  if (f8 && (d->dtype != DG_BF16 || !f8->xs || !f8->ws || d->Cred % 128)) return DG_ERR_BAD_SHAPE;
+  int rc = gg_validate(d, f8 != nullptr, im2col_small);
+  if (rc) return rc;
+  const int epc = f8 ? 16 : d->dtype == DG_F32 ? 4 : 8;
+  GGArgs a{};
+  a.x = x; a.w = w; a.y = y;
+  a.ldx = d->lds; a.ldw = d->ldw; a.ldy = d->ldd;
+  a.M = d->N * d->Hg * d->Wg; a.Hg = d->Hg; a.Wg = d->Wg; a.Hs = d->Hs; a.Ws = d->Ws;
+  a.Cred = d->Cred; a.cch = d->Cred / epc; a.ntaps = d->ntaps; a.kchunks = d->ntaps * a.cch;
+  a.sy_mul = d->sy_mul; a.sx_mul = d->sx_mul;
+  a.tap_lo = 0; a.tap_hi = 0;
+  for (int t = 0; t < d->ntaps; ++t) {
+    unsigned long long code = (unsigned)(d->tap_dy[t] + 1) | ((unsigned)(d->tap_dx[t] + 1) << 2) | ((unsigned)d->tap_w[t] << 4);
+    if (t < 8) a.tap_lo |= code << (8 * t); else a.tap_hi = (unsigned)code;
+  }
+  a.Nout = d->Nout; a.Hd = d->Hd; a.Wd = d->Wd;
+  a.dy_mul = d->dy_mul; a.dx_mul = d->dx_mul; a.dy_off = d->dy_off; a.dx_off = d->dx_off;
+  a.src_ps = d->src_ps; a.dst_ps = d->dst_ps;
+  a.cps_src_chunks = d->src_ps ? d->Cred / 4 / epc : 1;
+  a.cps_dst = d->dst_ps ? d->Nout / 4 : d->Nout;
+  a.s1 = a.s2 = 1.f; a.mask_slope = 1.f; a.act_slope = 1.f;
+  if (ep) {
+    a.bias = ep->bias; a.has_act = ep->has_act; a.act_slope = ep->act_slope;
+    a.r1 = ep->r1; a.ldr1 = ep->ldr1; a.s1 = ep->s1;
+    a.r2 = ep->r2; a.ldr2 = ep->ldr2; a.s2 = ep->s2;
+    a.mask = ep->mask; a.ldmask = ep->ldmask; a.mask_slope = ep->mask_slope;
+    a.mask_c0 = ep->mask_c0; a.mask_last = ep->mask_last;
+    if (a.mask_c0 < 0 || a.mask_c0 % 16 || ((a.mask_c0 || a.mask_last) && !a.mask)) return DG_ERR_BAD_ARG;
+    a.accumulate = ep->accumulate;
+    a.mask_bits = ep->mask_bits; a.out_bits = ep->out_bits;
+    a.out_q = ep->out_q; a.out_qs = ep->out_qs;
+    // the MXFP8 copy is written by the 64-channel wave-tile epilogues of bf16 launches: same shape rules as the bit masks
+    if ((a.out_q != nullptr) != (a.out_qs != nullptr)) return DG_ERR_BAD_ARG;
+    if (a.out_q && (d->dtype != DG_BF16 || d->Nout < 128 || d->Nout % 64 || d->dst_ps)) return DG_ERR_BAD_SHAPE;
+    a.ldqs = ep->ldqs > 0 ? (int)ep->ldqs : d->Nout / 32;
+    a.qs_shift = 0;
+    if (a.out_q && a.ldqs != d->Nout / 32) {        // strided scale rows: the kernel splits the mask-word index by a shift
+      const int n16 = d->Nout / 16;
+      if ((n16 & (n16 - 1)) || a.ldqs < d->Nout / 32) return DG_ERR_BAD_SHAPE;
+      while ((1 << a.qs_shift) < n16) ++a.qs_shift;
+    }
+    // bit masks need 64-channel wave tiles (Nout >= 128 selects them in every dispatch path) and plain destinations
+    if ((a.mask_bits || a.out_bits) && (d->Nout < 128 || d->Nout % 64 || d->dst_ps || (a.mask_bits && a.mask))) return DG_ERR_BAD_SHAPE;
+    if ((a.r1 && a.ldr1 % 4) || (a.r2 && a.ldr2 % 4) || (a.mask && a.ldmask % 4)) return DG_ERR_BAD_SHAPE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (f8) {
+    F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws, f8->ldxs > 0 ? (int)f8->ldxs : d->Cred / 32};
+    if (f.ldxs < d->Cred / 32 || f.ldxs % 4) return DG_ERR_BAD_SHAPE;          // the kernel fetches 4 scale bytes per pixel and K-step as one dword
+    return gg_launch_f8(a, f, d->N, st);
+  }
+  static const bool no_im2col = getenv("DG_GG_NOIM2COL") != nullptr;
+  if (im2col_small && !no_im2col) return gg_launch_im2col(a, d->dtype, st);
+  return gg_launch(a, d->dtype, d->N, st);
+}
+
+extern "C" int dg_gather_gemm(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w,
+                              void* y, void* stream) {
+  return gather_gemm_impl(d, ep, x, w, y, stream, false);
+}
+
+static int geom_validate(const dg_conv_geom* g) {
+  if (!g) return DG_ERR_BAD_ARG;
+  if (g->dtype != DG_F32 && g->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  if (g->N <= 0 || g->H <= 0 || g->W <= 0) return DG_ERR_BAD_SHAPE;
+  if (g->stride != 1 && g->stride != 2) return DG_ERR_BAD_SHAPE;
+  if (g->stride == 2 && ((g->H | g->W) & 1)) return DG_ERR_BAD_SHAPE;
+  if (g->Cin <= 0 || g->Cin % 8 || g->Cout <= 0 || g->Cout % 16) return DG_ERR_BAD_SHAPE;
+  if (g->pixel_shuffle && (g->stride != 1 || (g->Cout / 4) % 16)) return DG_ERR_BAD_SHAPE;
+  return DG_OK;
+}
+
+extern "C" int dg_conv3x3_plan(const dg_conv_geom* g, int kind, dg_gg_desc* out) {
+  int rc = geom_validate(g);
+  if (rc) return rc;
+  if (!out || (kind != 0 && kind != 1)) return DG_ERR_BAD_ARG;
+  const int Ho = g->H / g->stride, Wo = g->W / g->stride;
+  if (kind == 0) {
+    dg_gg_desc d{};
+    d.dtype = g->dtype; d.N = g->N; d.Hs = g->H; d.Ws = g->W; d.Cred = g->Cin; d.lds = g->ldx; d.src_ps = 0;
+    d.Hg = Ho; d.Wg = Wo; d.sy_mul = g->stride; d.sx_mul = g->stride;
+    d.ntaps = 9;
+    for (int r = 0; r < 3; ++r)
+      for (int s = 0; s < 3; ++s) { d.tap_dy[r * 3 + s] = r - 1; d.tap_dx[r * 3 + s] = s - 1; d.tap_w[r * 3 + s] = r * 3 + s; }
+    d.Nout = g->Cout; d.ldw = 9ll * g->Cin;
+    d.ldd = g->ldy; d.dy_mul = d.dx_mul = 1; d.dy_off = d.dx_off = 0;
+    if (g->pixel_shuffle) { d.dst_ps = 1; d.Hd = 2 * Ho; d.Wd = 2 * Wo; }
+    else { d.dst_ps = 0; d.Hd = Ho; d.Wd = Wo; }
+    out[0] = d;
+    return 1;
+  }
+  // data gradient: source = dy over the Ho x Wo output grid, destination = dx over H x W
+  int nd = 0;
+  const int st = g->stride;
+  for (int ph = 0; ph < st; ++ph)
+    for (int pw = 0; pw < st; ++pw) {
+      dg_gg_desc d{};
+      d.dtype = g->dtype; d.N = g->N; d.Hs = Ho; d.Ws = Wo; d.Cred = g->Cout; d.lds = g->ldy;
+      d.src_ps = g->pixel_shuffle;
+      d.Hg = g->H / st; d.Wg = g->W / st; d.sy_mul = 1; d.sx_mul = 1;
+      d.ntaps = 0;
+      for (int r = 0; r < 3; ++r) {
+        if ((ph + 1 - r) % st) continue;
+        for (int s = 0; s < 3; ++s) {
+          if ((pw + 1 - s) % st) continue;
+          // ho = (hi + 1 - r)/st with hi = gy*st + ph
+          d.tap_dy[d.ntaps] = (ph + 1 - r) / st; d.tap_dx[d.ntaps] = (pw + 1 - s) / st;
+          d.tap_w[d.ntaps] = r * 3 + s;
+          ++d.ntaps;
+        }
+      }
+      d.Nout = g->Cin; d.ldw = 9ll * g->Cout;
+      d.Hd = g->H; d.Wd = g->W; d.ldd = g->ldx;
+      d.dy_mul = d.dx_mul = st; d.dy_off = ph; d.dx_off = pw; d.dst_ps = 0;
+      out[nd++] = d;
+    }
+  return nd;
+}
+
+extern "C" int dg_conv3x3_fwd(const dg_conv_geom* g, const dg_epilogue* ep, const void* x, const void* w_fwd,
+                              void* y, void* stream) {
+  dg_gg_desc d[4];
+  g_last_kinds = 0;
+  int n = dg_conv3x3_plan(g, 0, d);
+  if (n < 0) return n;
+  const bool small = g->cin_real > 0 && g->cin_real <= 2 && g->stride == 1 && !g->pixel_shuffle;
+  return gather_gemm_impl(&d[0], ep, x, w_fwd, y, stream, small);
+}
+
+extern "C" int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, const void* dy, const void* w_dgrad,
+                                void* dx, void* stream) {
+  if (g && g->Cin % 16) return DG_ERR_BAD_SHAPE;  // dx channels are a GEMM N dimension
+  dg_gg_desc d[4];
+  g_last_kinds = 0;
+  int n = dg_conv3x3_plan(g, 1, d);
+  if (n < 0) return n;
+  for (int i = 0; i < n; ++i) {
+    int rc = dg_gather_gemm(&d[i], ep, dy, w_dgrad, dx, stream);
+    if (rc) return rc;
+  }
+  return DG_OK;
+}
+
+// MXFP8 operands (csrc/quant.hip), bf16 output / epilogue tensors.  q->ldxq replaces the source's pixel stride of `g`.
+extern "C" int dg_conv3x3_fwd_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* y, void* stream) {
+  if (!q || !g || g->dtype != DG_BF16 || g->pixel_shuffle || g->Cin % 128) return DG_ERR_BAD_SHAPE;
+  dg_gg_desc d[4];
+  g_last_kinds = 0;
+  int n = dg_conv3x3_plan(g, 0, d);
+  if (n < 0) return n;
+  d[0].lds = q->ldxq;
+  return gather_gemm_impl(&d[0], ep, q->xq, q->wq, y, stream, false, q);
+}
+
+extern "C" int dg_conv3x3_dgrad_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* dx, void* stream) {
+  if (!q || !g || g->dtype != DG_BF16 || g->pixel_shuffle || g->Cout % 128 || g->Cin % 16) return DG_ERR_BAD_SHAPE;
+  dg_gg_desc d[4];
+  g_last_kinds = 0;
+  int n = dg_conv3x3_plan(g, 1, d);
+  if (n < 0) return n;
+  for (int i = 0; i < n; ++i) {
+    d[i].lds = q->ldxq;
+    int rc = gather_gemm_impl(&d[i], ep, q->xq, q->wq, dx, stream, false, q);
+    if (rc) return rc;
+  }
+  return DG_OK;
+}
+
+extern "C" int dg_last_conv_kernels(void) { return g_last_kinds; }

@@ -102,7 +102,7 @@ extern "C" int dg_gp_interp(int dtype, const void* real, const void* fake, const
 }
 
 // The 2-channel fields of the fine grid (wasserstein.py:94: real, fake, interpolate) are stored 16 channels wide like every
-// activation; the critic's first layer reads the two real channels only, and its gathers are what bounds it (csrc/gather_gemm.hip,
+// activation; the critic's first layer reads the two real channels only, and its gathers are what bounds it (csrc/conv_small.hip,
 // gg_im2col_direct_kernel: 0.79 -> 0.62 ms per 8 images from a compact [pixel][2] source).  These two kernels write the COMPACT
 // forms where the bytes are produced anyway: the interpolate (plus compact copies of its two inputs, which it has in registers)
 // and the penalty's scaled gradient.  One thread = 16 bytes of each output (4 bf16 / 2 fp32 pixels).

@@ -813,7 +813,7 @@ class TrainEngine:
         assert self.C.c_pad[0] == self.G.np_p
         o = ops
         # Fields of the fine grid are stored np_p (16) channels wide like every activation.  With <= 2 predictands the critic's
-        # first layer reads two real channels and its kernels are gather-bound on that layout (csrc/gather_gemm.hip:
+        # first layer reads two real channels and its kernels are gather-bound on that layout (csrc/conv_small.hip:
         # gg_im2col_direct_kernel), so everything it reads also exists in COMPACT form [B, fine, fine, 2], written where the bytes
         # are produced anyway: the interpolate x-hat and the penalty's scaled gradient are compact only, and the interpolate pass
         # also leaves compact copies of its two inputs (the real and the generated batch) for their own critic passes.

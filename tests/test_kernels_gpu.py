@@ -523,26 +523,6 @@ def test_mask_bits_rejected_for_narrow_layers():
                      out_bits=torch.zeros(1, 16, 16, 1, 4, dtype=torch.int16, device="cuda"))
 
 
-def test_previous_generation_halo_kernels_in_a_subprocess():
-    """The eight-wave halo kernel (plain, stride-2, channel-tile modes) stays in the tree behind DG_GG_NO4W=1; the switch is
-    read once per process, so it is exercised in ONE child process on a few shapes of this module's forward / data-gradient
-    tests."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, DG_GG_NO4W="1")
-    code = (
-        "import tests.test_kernels_gpu as t\n"
-        "for cfg in [(2, 8, 8, 128, 128, 1, False), (1, 16, 16, 128, 256, 2, False), (1, 32, 48, 128, 256, 1, False),\n"
-        "            (1, 32, 32, 128, 512, 1, True), (2, 48, 80, 256, 128, 2, False)]:\n"
-        "    for dt in ('f32', 'bf16'):\n"
-        "        t.test_conv_fwd(dt, cfg); t.test_conv_dgrad(dt, cfg)\n"
-        "print('previous-generation kernels ok')\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "previous-generation kernels ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_small_cout_backward_on_first_layer_kernels(dtype):
     """A stride-1 layer with <= 2 real OUTPUT channels (generator conv3.2, generator.py:80): its data gradient as the forward conv
