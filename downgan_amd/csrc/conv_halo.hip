@@ -63,8 +63,15 @@ bool gg_regroup_taps_by_plane(GGArgs& a) {
 // the second), one workgroup per CU.  Both channel halves read ONE patch, so the patch bytes per flop halve -- which is what
 // bounds the stride-2 forward (a stride-2 tile reads 4x the input pixels of a stride-1 tile: 227 flop per patch byte at 128
 // channels, and the per-CU global->LDS path sustains only ~10-12 B/clk) -- at the price of the second, independent workgroup.
-template <typename T, bool S2, bool PS = false, int NW = 4>
+// SEG: the data gradient of a stride-2 layer as ONE launch.  Its four output-parity classes (1 / 2 / 2 / 4 taps, conv_plan.hip) all
+// read dy and write the four interleaved pixel sets of dx.  As four launches each re-reads dy from HBM (features.2 at batch 32:
+// 2.1 GB, far beyond the 256 MB Infinity Cache; 17.7 GB moved for 11.3 GB algorithmic).  Here a workgroup still computes ONE class of
+// one tile, but the launch covers (image, class, tile) in that order and workgroups keep their launch order (no XCD-contiguous
+// remap): the chip works through one image's four classes back to back, so classes 2-4 find that image's dy (67 MB) in the
+// Infinity Cache, and the three inter-launch tails go away.  a.tap_* hold the classes' taps concatenated (9 in all).
+template <typename T, bool S2, bool PS = false, int NW = 4, bool SEG = false>
 __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, int tiles_x, int tiles_y) {
+  static_assert(!SEG || (!S2 && !PS && NW == 4), "SEG is a mode of the plain four-wave kernel");
   constexpr int NT = 64 * NW, RPP = NT / 8;                              // threads; patch rows staged per pass
   constexpr int EPC = DT<T>::EPC;
   constexpr int ES = (int)sizeof(T);
@@ -79,12 +86,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
   char* const s_w = dsm4w + PROWS * PITCH;        // [2][BC][WROW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const unsigned tile = SEG ? blockIdx.x : xcd_remap(blockIdx.x, a.nwg);
   const int tile_c = tile % a.nct;
   unsigned rest = tile / a.nct;
   const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
-  const int ty0 = (rest % tiles_y) * TH;
-  const int img = rest / tiles_y;
+  const int ty0 = (rest % tiles_y) * TH; rest /= tiles_y;
+  const int cls = SEG ? (int)(rest & 3u) : 0;          // parity class (py, px) = (cls >> 1, cls & 1)
+  const int img = SEG ? (int)(rest >> 2) : (int)rest;
+  const int ntaps_l = SEG ? (0x4221 >> (4 * cls)) & 15 : a.ntaps;        // this workgroup's taps: [tap0_l, tap0_l + ntaps_l) of a.tap_*
+  const int tap0_l = SEG ? (0x5310 >> (4 * cls)) & 15 : 0;
   const int c0 = tile_c * BC;
   const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0, RPP)
   const int wq = wave & 3, wh = wave >> 2;        // tile rows 4*wq.., channel half wh (0 unless NW = 8)
@@ -95,9 +105,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
   const int l15 = lane & 15, g = lane >> 4;
   const int ncbr = a.cch / KC;                    // real channel blocks
   const int ncb = S2 ? 4 * ncbr : ncbr;           // (plane, channel block) pairs, plane-major
-  const int nsteps = ncbr * a.ntaps;
+  const int nsteps = ncbr * ntaps_l;
   auto plane_of = [&](int vcb) { return S2 ? (int)(vcb >= ncbr) + (int)(vcb >= 2 * ncbr) + (int)(vcb >= 3 * ncbr) : 0; };
-  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : a.ntaps; };
+  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : ntaps_l; };
 
   unsigned woff[NWL];                             // DMA piece i of this wave: rows wave*32 + 8i .. +7, lane = (row, physical chunk)
 #pragma unroll
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
     woff[i] = (unsigned)((long long)row * a.ldw * ES) + logical * 16;
   }
   auto tap_code = [&](int vcb, int tap) {
-    const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap;
+    const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap0_l + tap;
     return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
   };
   u32x4_t rp[NPL];
@@ -119,7 +129,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
     const int psq = PS ? (cb * KC) / a.cps_src_chunks : 0;                 // channel quarter of this block
     const int psy = psq >> 1, psx = psq & 1;
     const long long cboff = PS ? (long long)(cb * KC - psq * a.cps_src_chunks) * EPC * ES : (long long)cb * KC * EPC * ES;
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + cboff), 0, (int)DG_OOB_OFF, 0x00020000);
+    // the descriptor base is workgroup-uniform, but derived from the (plane, channel block) counter the compiler does not prove
+    // uniform: without the readfirstlane pair every one of the NPL loads below sits in its own waterfall loop (S2 / PS instances)
+    const unsigned long long xbase = (unsigned long long)(Xb + cboff);
+    const unsigned long long xuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xuni, 0, (int)DG_OOB_OFF, 0x00020000);
     int r0v = r0;
     asm volatile("" : "+v"(r0v));
 #pragma unroll
@@ -280,7 +295,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
   unsigned long long tL1, tX;
   STAMP(tL1);
 #endif
-  halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
+  if constexpr (SEG) halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, cls >> 1, cls & 1);
+  else halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
 #ifdef DG_STAMP
   STAMP(tX);
   if (blockIdx.x < 2 && lane == 0) {
@@ -290,20 +306,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
 #endif
 }
 
-template <typename T, bool S2, bool PS = false, int NW = 4>
+template <typename T, bool S2, bool PS = false, int NW = 4, bool SEG = false>
 static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
   constexpr int BC = 32 * NW;
   constexpr int LDS_BYTES = 324 * 144 + 2 * BC * 128;
-  DG_SET_MAX_LDS_ONCE((&gg_halo4w_kernel<T, S2, PS, NW>), LDS_BYTES);
+  DG_SET_MAX_LDS_ONCE((&gg_halo4w_kernel<T, S2, PS, NW, SEG>), LDS_BYTES);
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
   a.nct = (unsigned)((a.Nout + BC - 1) / BC);
-  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N) * (SEG ? 4u : 1u);
   g_last_kinds |= 8;
-  hipLaunchKernelGGL((gg_halo4w_kernel<T, S2, PS, NW>), dim3(a.nwg), dim3(64 * NW), LDS_BYTES, st, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL((gg_halo4w_kernel<T, S2, PS, NW, SEG>), dim3(a.nwg), dim3(64 * NW), LDS_BYTES, st, a, tiles_x, tiles_y);
   return dg_check_launch();
 }
 
 int gg_launch_halo(GGArgs& a, int dtype, int N, bool s2, bool ps, int nw, hipStream_t st) {
+  if (a.seg) return dtype == DG_BF16 ? gg_launch_halo4w<bf16_t, false, false, 4, true>(a, N, st) : gg_launch_halo4w<float, false, false, 4, true>(a, N, st);
   if (dtype == DG_F32) {
     if (ps) return gg_launch_halo4w<float, false, true>(a, N, st);
     return s2 ? gg_launch_halo4w<float, true>(a, N, st) : gg_launch_halo4w<float, false>(a, N, st);

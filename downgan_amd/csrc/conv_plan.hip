@@ -72,7 +72,7 @@ static int gg_launch_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st) {
   return DG_ERR_BAD_SHAPE;
 }
 static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w, void* y, void* stream,
-                            bool im2col_small, const dg_f8_operands* f8 = nullptr) {
+                            bool im2col_small, const dg_f8_operands* f8 = nullptr, bool seg = false) {
   if (!d || !x || !w || !y) return DG_ERR_BAD_ARG;
   if (f8 && (d->dtype != DG_BF16 || !f8->xs || !f8->ws || d->Cred % 128)) return DG_ERR_BAD_SHAPE;
   int rc = gg_validate(d, f8 != nullptr, im2col_small);
@@ -120,6 +120,7 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     if ((a.r1 && a.ldr1 % 4) || (a.r2 && a.ldr2 % 4) || (a.mask && a.ldmask % 4)) return DG_ERR_BAD_SHAPE;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  a.seg = seg ? 1 : 0;
   if (f8) {
     F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws, f8->ldxs > 0 ? (int)f8->ldxs : d->Cred / 32};
     if (f.ldxs < d->Cred / 32 || f.ldxs % 4) return DG_ERR_BAD_SHAPE;          // the kernel fetches 4 scale bytes per pixel and K-step as one dword
@@ -203,6 +204,25 @@ extern "C" int dg_conv3x3_fwd(const dg_conv_geom* g, const dg_epilogue* ep, cons
   return gather_gemm_impl(&d[0], ep, x, w_fwd, y, stream, small);
 }
 
+// The four parity-class descriptors of a stride-2 data gradient as ONE descriptor for the merged launch of the halo kernel
+// (conv_halo.hip, SEG): the classes' taps concatenated in class order (1 / 2 / 2 / 4); the destination offset is the workgroup's
+// class parity.  Any epilogue; whole 64-channel reduction blocks (8 chunks), > 64 outputs, tiles of >= 8 x 8.
+static bool seg_dgrad_desc(const dg_gg_desc* d, int n, dg_gg_desc* out) {
+  static const bool off = getenv("DG_GG_NOSEG") != nullptr;
+  const int epc = d[0].dtype == DG_F32 ? 4 : 8;
+  if (off || n != 4 || d[0].src_ps || d[0].dst_ps || (d[0].Cred / epc) % 8 || d[0].Nout <= 64 || d[0].Hg < 8 || d[0].Wg < 8) return false;
+  if (d[0].ntaps != 1 || d[1].ntaps != 2 || d[2].ntaps != 2 || d[3].ntaps != 4) return false;
+  *out = d[3];
+  out->ntaps = 0;
+  for (int c = 0; c < 4; ++c) {
+    if (d[c].dy_off != (c >> 1) || d[c].dx_off != (c & 1) || d[c].dy_mul != 2 || d[c].dx_mul != 2) return false;
+    for (int t = 0; t < d[c].ntaps; ++t, ++out->ntaps) {
+      out->tap_dy[out->ntaps] = d[c].tap_dy[t]; out->tap_dx[out->ntaps] = d[c].tap_dx[t]; out->tap_w[out->ntaps] = d[c].tap_w[t];
+    }
+  }
+  return out->ntaps == 9;
+}
+
 extern "C" int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, const void* dy, const void* w_dgrad,
                                 void* dx, void* stream) {
   if (g && g->Cin % 16) return DG_ERR_BAD_SHAPE;  // dx channels are a GEMM N dimension
@@ -210,6 +230,8 @@ extern "C" int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, co
   g_last_kinds = 0;
   int n = dg_conv3x3_plan(g, 1, d);
   if (n < 0) return n;
+  dg_gg_desc ds;
+  if (seg_dgrad_desc(d, n, &ds)) return gather_gemm_impl(&ds, ep, dy, w_dgrad, dx, stream, false, nullptr, true);
   for (int i = 0; i < n; ++i) {
     int rc = dg_gather_gemm(&d[i], ep, dy, w_dgrad, dx, stream);
     if (rc) return rc;

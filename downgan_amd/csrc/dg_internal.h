@@ -77,6 +77,19 @@ __device__ __forceinline__ dg_u32x4_t pack_fp8x16(const float* v, float inv) {
   }
   return o;
 }
+// A block that holds a NaN or an Inf is written as 16 x 0x7F (E4M3 NaN): the clamp above would launder a NaN into -448 and an
+// Inf into +-448, and every later fp8 layer reads only the quantised copy.  `amax_bits` = unsigned maximum of the block's
+// magnitude bit patterns (equal to the bits of the float maximum for finite values; any NaN / Inf pattern is >= 0x7f800000).
+__device__ __forceinline__ dg_u32x4_t mx_poison(dg_u32x4_t q, unsigned amax_bits) {
+  if (amax_bits >= 0x7f800000u) q = dg_u32x4_t{0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu};
+  return q;
+}
+__device__ __forceinline__ unsigned mx_amax_bits16(const float* v) {
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { const unsigned u = __float_as_uint(v[k]) & 0x7fffffffu; m = u > m ? u : m; }
+  return m;
+}
 // E8M0 scale byte of an MX block with maximum magnitude amax: 2^(floor(log2 amax) - 8) (8 = emax of E4M3), biased by 127
 __device__ __forceinline__ int mx_scale_byte(float amax) {
   const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;

@@ -54,6 +54,7 @@ struct GGArgs {
   float act_slope, s1, s2, mask_slope;
   unsigned nwg, nct;
   int mask_c0, mask_last;                      // dg_epilogue: mask for channels >= mask_c0 only, applied after the accumulate
+  int seg;                                     // 1: the four parity classes of a stride-2 data gradient in ONE launch (conv_halo.hip, SEG)
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -432,12 +433,14 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
 // (one multiply-add per fragment and tensor instead of 64-bit index arithmetic), and out-of-tile / out-of-range
 // fragments get an out-of-range offset: the hardware drops those stores and returns zeros for those loads, so the
 // epilogue has no divergent branches.
+// oy_o / ox_o >= 0: destination offsets of this workgroup instead of a.dy_off / a.dx_off (the parity class of a merged stride-2
+// data-gradient launch, conv_halo.hip SEG).
 template <typename T, int NH>
 __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 * NH][4], int img, int ty0, int tx0, int c0, int wp,
-                                              int wc, int l15, int g) {
+                                              int wc, int l15, int g, int oy_o = -1, int ox_o = -1) {
   constexpr int ES = (int)sizeof(T);
   const int psm = a.dst_ps ? 2 : a.dy_mul, psx = a.dst_ps ? 2 : a.dx_mul;
-  const int oy = a.dst_ps ? 0 : a.dy_off, ox = a.dst_ps ? 0 : a.dx_off;
+  const int oy = oy_o >= 0 ? oy_o : (a.dst_ps ? 0 : a.dy_off), ox = ox_o >= 0 ? ox_o : (a.dst_ps ? 0 : a.dx_off);
   // workgroup base pixel (scalar) and this lane's relative pixel for tile row wp*4 (+ i rows of pitch `rowp`)
   const long long pb = ((long long)img * a.Hd + (long long)ty0 * psm + oy) * a.Wd + (long long)tx0 * psx + ox;
   const int rel0 = (wp * 4) * psm * a.Wd + l15 * psx;

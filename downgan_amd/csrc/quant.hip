@@ -9,7 +9,8 @@
 // channels 16g.. and 64 + 16g.. in place, the four scale blocks are channels [0,32) [32,64) [64,96) [96,128) of the row, and
 // lane (r, g) supplies the scale of block g.
 // scale byte s: value 2^(s - 127); chosen as 2^(floor(log2(amax)) - 8) (8 = emax of E4M3, OCP MX rule); elements are
-// x / scale rounded to nearest even, saturated at +-448.
+// x / scale rounded to nearest even, saturated at +-448.  A block that holds a NaN or an Inf becomes 32 x NaN (0x7F), so a
+// non-finite activation or adjoint stays visible down the fp8 chain instead of being clamped into a finite value.
 #include "dg_internal.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned int q_u32x4_t;
@@ -49,13 +50,12 @@ __global__ void __launch_bounds__(256) quant_mxfp8_kernel(const T* __restrict__ 
     float v[32];
     QLoad<T>::run(src + r * ld + c_lo, v);
     QLoad<T>::run(src + r * ld + c_lo + 16, v + 16);
-    float amax = 0.f;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[k]));
-    const int e = mx_scale_byte(amax);
+    const unsigned a0 = mx_amax_bits16(v), a1 = mx_amax_bits16(v + 16);
+    const unsigned ab = a0 > a1 ? a0 : a1;                       // a NaN / Inf anywhere in the block dominates
+    const int e = mx_scale_byte(__uint_as_float(ab));
     const float inv = mx_inv_scale(e);
-    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo) = pack_fp8x16(v, inv);
-    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo + 16) = pack_fp8x16(v + 16, inv);
+    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo) = mx_poison(pack_fp8x16(v, inv), ab);
+    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + c_lo + 16) = mx_poison(pack_fp8x16(v + 16, inv), ab);
     sc[r * ldqs + b] = (unsigned char)e;
   }
 }

@@ -163,9 +163,11 @@ class EmuOps:
         amax = v.abs().amax(-1)
         e = (((amax.contiguous().view(torch.int32) >> 23) & 0xff) - 8).clamp(min=0)
         scale = torch.ldexp(torch.ones_like(amax), e - 127)
-        q8 = (v / scale[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
-        deq = q8.float() * scale[..., None]
-        return (q8.view(torch.uint8).reshape(x.shape), e.to(torch.uint8).reshape(tuple(x.shape[:-1]) + (Cc // 32,)), deq.reshape(x.shape))
+        q8 = (v / scale[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        # a block that holds a NaN / Inf is written as 32 x NaN (0x7F) -- csrc/dg_internal.h mx_poison
+        q8 = torch.where(torch.isfinite(amax)[..., None], q8, torch.full_like(q8, 0x7F))
+        deq = q8.view(torch.float8_e4m3fn).float() * scale[..., None]
+        return (q8.reshape(x.shape), e.to(torch.uint8).reshape(tuple(x.shape[:-1]) + (Cc // 32,)), deq.reshape(x.shape))
 
     def quant_mxfp8(self, src, q=None, scales=None):
         qq, ss, _ = self.mx_quant(src)

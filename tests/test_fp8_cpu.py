@@ -32,6 +32,14 @@ def test_mx_quant_format():
     assert float(d[1, 3]) == 448 * 2.0 ** (int(s[1, 0]) - 127) or abs(float(d[1, 3]) - 1e4) <= 1e4 * 2.0 ** -4
 
 
+def test_mx_quant_poisons_nonfinite_blocks():
+    x = torch.randn(4, 128)
+    x[1, 40] = float("nan"); x[2, 100] = float("inf")
+    q, s, deq = EmuOps.mx_quant(x)
+    assert bool((q[1, 32:64] == 0x7F).all()) and bool((q[2, 96:128] == 0x7F).all()) and int((q == 0x7F).sum()) == 64
+    assert bool(torch.isnan(deq[1, 32:64]).all()) and bool(torch.isfinite(deq[0]).all()) and bool(torch.isfinite(deq[1, :32]).all())
+
+
 def test_engine_fp8_mode_only_touches_wide_critic_convs():
     """F = 128 critic on a 64x64 tile, emulated: fp8 mode changes the critic's scalars a little, and not at all when no
     layer is eligible (the generator never is)."""

@@ -39,6 +39,40 @@ def test_quantiser_matches_emulation_bit_for_bit(src_dtype):
     assert torch.equal(q2.cpu(), q2r) and torch.equal(s2.cpu(), s2r)
 
 
+def test_quantiser_keeps_nan_and_inf_visible():
+    """A NaN or an Inf must not be clamped into a finite fp8 value (every later fp8 layer reads only the quantised copy): the
+    whole 32-channel block becomes E4M3 NaN -- stand-alone quantiser and fused conv epilogue alike, bit-equal to the emulation --
+    and an fp8 conv fed such a block returns NaN for the pixels that read it."""
+    hip = HipOps("bf16", f8_critic=True)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 8, 256, generator=g).to(torch.bfloat16)
+    x[0, 1, 2, 37] = float("nan"); x[1, 3, 3, 200] = float("inf"); x[1, 7, 0, 64] = float("-inf")
+    q_ref, s_ref, deq = EmuOps.mx_quant(x)
+    q, s = hip.quant_mxfp8(x.cuda())
+    assert torch.equal(q.cpu(), q_ref) and torch.equal(s.cpu(), s_ref)
+    for (n, h, w, c) in ((0, 1, 2, 37), (1, 3, 3, 200), (1, 7, 0, 64)):
+        blk = q.cpu()[n, h, w, 32 * (c // 32):32 * (c // 32) + 32]
+        assert bool((blk == 0x7F).all()) and bool(torch.isnan(deq[n, h, w, c]))
+    assert int((q.cpu() == 0x7F).sum()) == 3 * 32                      # nothing else was touched
+    # fused epilogue: a conv whose OUTPUT has a NaN (NaN bias -> every pixel of that channel) writes NaN blocks in its fp8 copy
+    cv = Conv(1, 16, 16, 128, 128, 1, False)
+    xin = torch.randn(1, 16, 16, 128, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(128 * 9 * 128, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    b = torch.zeros(128); b[70] = float("nan")
+    y = torch.zeros(1, 16, 16, 128, dtype=torch.bfloat16).cuda()
+    oq = (torch.zeros(1, 16, 16, 128, dtype=torch.uint8).cuda(), torch.zeros(1, 16, 16, 4, dtype=torch.uint8).cuda())
+    hip.conv_fwd(cv, xin, w, y, bias=b.cuda(), out_q=oq)
+    assert bool(torch.isnan(y[..., 70].float()).all())
+    assert bool((oq[0][..., 64:96] == 0x7F).all()) and not bool((oq[0][..., :64] == 0x7F).all())
+    q2, s2 = hip.quant_mxfp8(y)
+    assert torch.equal(oq[0], q2) and torch.equal(oq[1], s2)
+    # and the next fp8 layer sees it: NaN in, NaN out
+    cvn = Conv(1, 16, 16, 128, 128, 1, False, net="C")
+    out = torch.zeros(1, 16, 16, 128, dtype=torch.bfloat16).cuda()
+    hip.conv_fwd(cvn, y, w, out, xq=oq)
+    assert bool(torch.isnan(out.float()).all())
+
+
 F8_CONVS = [
     # N, H, W, Cin, Cout, stride  -- the critic's wide layers at cfg2 widths (critic.py:25-88), small grids; ragged tiles
     (1, 32, 32, 128, 128, 2),
