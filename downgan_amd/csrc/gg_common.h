@@ -250,12 +250,11 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
     if (f_q) {
       float w[16];
       IO::unpack(pk[0], w); IO::unpack(pk[1], w + 8);
-      float amax = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(w[k]));
-      amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
-      const int e = mx_scale_byte(amax);
-      const u32x4_t qv = __builtin_bit_cast(u32x4_t, pack_fp8x16(w, mx_inv_scale(e)));
+      unsigned ab = mx_amax_bits16(w);                                // (a NaN / Inf in the block dominates: mx_poison)
+      const unsigned ab2 = (unsigned)__shfl_xor((int)ab, 16, 64);
+      ab = ab > ab2 ? ab : ab2;
+      const int e = mx_scale_byte(__uint_as_float(ab));
+      const u32x4_t qv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, mx_inv_scale(e)), ab));
       __builtin_amdgcn_raw_buffer_store_b128(qv, R.rq, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
       const bool low_half = ((threadIdx.x >> 4) & 1) == 0;
       unsigned offqs = boff >> 2;                                   // dense scale rows: (rel * Nout + channel) / 32
