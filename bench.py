@@ -179,9 +179,13 @@ def build_engine(args, dtype, world, dist, local, rank, nsteps):
     is_f8 = dtype in ("fp8", "fp8c")
     ops = HipOps("bf16" if is_f8 else dtype, f"cuda:{local}", f8_critic=is_f8, f8_generator=dtype == "fp8")
     eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B * world), num_res_blocks=nrb, dist=dist, check_finite=args.check_finite)
-    eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))       # seed 0 on every rank
-    eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
+    pg, pc = synthetic.generator_params(F_, cin, 2, nrb), synthetic.critic_params(F_, 8 * S, 2)      # seed 0 on every rank
     coarse, fine = synthetic.tiles(B, cin, S, rank=rank)                      # seed 1234 + rank
+    if args.zero_data:
+        pg, pc = {k: v * 0 for k, v in pg.items()}, {k: v * 0 for k, v in pc.items()}
+        coarse, fine = coarse * 0, fine * 0
+    eng.G.load_state_dict(pg)
+    eng.C.load_state_dict(pc)
     xc = ops.zeros(B, S, S, eng.G.cin_p); ops.nchw_to_nhwc(torch.from_numpy(coarse).cuda(), xc)
     xf = ops.zeros(B, 8 * S, 8 * S, eng.G.np_p); ops.nchw_to_nhwc(torch.from_numpy(fine).cuda(), xf)
     del coarse, fine
@@ -296,6 +300,9 @@ def main():
     ap.add_argument("--check-finite", action="store_true",
                     help="debug: after every iteration one fused isfinite reduction over the scalars, the gradient buffers and the generated "
                          "batch; raises naming the first offending buffer (the stand-in for the reference's set_detect_anomaly, wasserstein.py:13)")
+    ap.add_argument("--zero-data", action="store_true",
+                    help="diagnostic: all-zero tiles AND weights (same launches, same cycles; shows how much of the distance to the MFMA "
+                         "peak is the clock the chip holds on random data -- MI355X_MICROARCH.md, DVFS give-back); never a benchmark result")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gradient exchange goes over gloo")
     args = ap.parse_args()
@@ -385,7 +392,7 @@ def main():
             "metric": "train-step samples/sec (G+D+GP)", "value": round(value, 4), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "ZEROS (clock diagnostic, not a result)" if args.zero_data else "synthetic",
             "rehearsal": bool(args.rehearse_on_one_gpu),
             "config": {"workload": f"{args.workload}: batch {B}/GPU (global {B * world}), {cin}ch {S}x{S}->{8 * S}x{8 * S}, "
                                    f"filters {F_}, {nrb} RRDBs, WGAN-GP critic step every step + generator step every 5th",

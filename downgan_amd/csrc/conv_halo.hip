@@ -90,9 +90,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
   const int tile_c = tile % a.nct;
   unsigned rest = tile / a.nct;
   const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
+  // SEG order: a.seg == 1: (image, class, tile row, tile column); a.seg == 2: (image, tile row, class, tile column) -- the four
+  // classes of one row of tiles back to back, so store-bound 1-tap and MFMA-bound 4-tap workgroups share the chip at any time
+  int cls = 0;
+  if (SEG && a.seg == 2) { cls = (int)(rest & 3u); rest >>= 2; }
   const int ty0 = (rest % tiles_y) * TH; rest /= tiles_y;
-  const int cls = SEG ? (int)(rest & 3u) : 0;          // parity class (py, px) = (cls >> 1, cls & 1)
-  const int img = SEG ? (int)(rest >> 2) : (int)rest;
+  if (SEG && a.seg != 2) { cls = (int)(rest & 3u); rest >>= 2; }    // parity class (py, px) = (cls >> 1, cls & 1)
+  const int img = (int)rest;
   const int ntaps_l = SEG ? (0x4221 >> (4 * cls)) & 15 : a.ntaps;        // this workgroup's taps: [tap0_l, tap0_l + ntaps_l) of a.tap_*
   const int tap0_l = SEG ? (0x5310 >> (4 * cls)) & 15 : 0;
   const int c0 = tile_c * BC;

@@ -121,6 +121,10 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   a.seg = seg ? 1 : 0;
+  if (seg) {     // (experiment switch: class order of the merged stride-2 data-gradient launch, conv_halo.hip)
+    static const int seg_order = getenv("DG_SEG_ORDER") ? atoi(getenv("DG_SEG_ORDER")) : 0;
+    if (seg_order == 2 || (seg_order == 3 && (long long)d->Cred * d->Nout * 18 <= (2ll << 20))) a.seg = 2;
+  }
   if (f8) {
     F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws, f8->ldxs > 0 ? (int)f8->ldxs : d->Cred / 32};
     if (f.ldxs < d->Cred / 32 || f.ldxs % 4) return DG_ERR_BAD_SHAPE;          // the kernel fetches 4 scale bytes per pixel and K-step as one dword
