@@ -121,9 +121,12 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   a.seg = seg ? 1 : 0;
-  if (seg) {     // (experiment switch: class order of the merged stride-2 data-gradient launch, conv_halo.hip)
+  if (seg) {
+    // class order of the merged stride-2 data-gradient launch (conv_halo.hip): classes interleaved per row of tiles while the nine
+    // weight taps of the layer fit an XCD's L2 beside everything else (<= 2 MB: the 128- and 256-channel layers, +3-4 %), else one
+    // class per image at a time (512 / 1024 channels: interleaved classes stream four tap sets at once, -2 %).  DG_SEG_ORDER=1|2 forces one.
     static const int seg_order = getenv("DG_SEG_ORDER") ? atoi(getenv("DG_SEG_ORDER")) : 0;
-    if (seg_order == 2 || (seg_order == 3 && (long long)d->Cred * d->Nout * 18 <= (2ll << 20))) a.seg = 2;
+    if (seg_order == 2 || (seg_order == 0 && (long long)d->Cred * d->Nout * 18 <= (2ll << 20))) a.seg = 2;
   }
   if (f8) {
     F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws, f8->ldxs > 0 ? (int)f8->ldxs : d->Cred / 32};
