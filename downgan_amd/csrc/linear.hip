@@ -258,8 +258,12 @@ __global__ __launch_bounds__(256, 2) void lin_dx_wide_kernel(const float* __rest
   auto read_row = [&](f4_t (&dst)[BG / 4], int o) {
     const unsigned adr = lds0 + (unsigned)o * (BG * 4);
 #pragma unroll
-    for (int q = 0; q < BG / 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[q]) : "v"(adr), "n"(16 * q));
+    for (int q = 0; q < BG / 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst[q]) : "v"(adr), "n"(16 * q));
   };
+  // (the hardware does not interlock a register that an LDS read is still filling: between `read_row` and `landed` the values
+  // must not be touched.  The compiler sees them as defined by the read asm, so a copy it inserted in between would read early;
+  // tests/test_kernels_gpu.py::test_linear_dx_wide_kernel_shapes compares the kernel against the oracle at every row count /
+  // ragged shape and is the guard against such a codegen change)
   auto landed = [&](f4_t (&dst)[BG / 4]) {          // all but the eight reads issued after this row's (LDS returns in order)
     asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]), "+v"(dst[5]), "+v"(dst[6]), "+v"(dst[7]));
   };
