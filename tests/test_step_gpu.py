@@ -224,6 +224,22 @@ def test_bf16_drift_at_full_tile_vs_fp32_native():
     assert all(v < 0.1 for v in drift.values())
 
 
+def test_bf16_learning_curve_tracks_fp32_on_a_learnable_task():
+    """Beyond the first steps: on a LEARNABLE task (fine = bilinear x8 of the coarse field + a fixed pattern, a new batch every
+    step; tools/train_drift.py) the content loss at the six generator steps of a 30-step run is the same in bf16 (the benchmarked
+    precision) as in the fp32-parity mode to 5e-3 relative (observed <= 2e-4; the 200-step curves are in
+    profiles/train_drift_learnable.json).  On the benchmark's pure-noise tiles the step is chaotic and no such comparison exists."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_drift", os.path.join(root, "tools", "train_drift.py"))
+    td = importlib.util.module_from_spec(spec); spec.loader.exec_module(td)
+    res = td.compare(steps=30, B=4, S=32, F_=128, cin=2, nrb=2, modes=("f32", "bf16"))
+    a = [v for _, v in res["runs"]["f32"]["content_loss_generator_steps"]]
+    b = [v for _, v in res["runs"]["bf16"]["content_loss_generator_steps"]]
+    assert len(a) == 6 and all(abs(x - y) <= 5e-3 * x for x, y in zip(a, b)), (a, b)
+    assert all(abs(x - y) <= 2e-2 * max(abs(x), 1.0) for x, y in zip(res["runs"]["f32"]["critic_loss"][:10], res["runs"]["bf16"]["critic_loss"][:10]))
+
+
 def test_hip_graph_replay_equals_eager():
     """critic / generator iterations captured into HIP graphs reproduce the eager launches (cfg1, 6 steps, fp32:
     only the order of the fp32 atomic accumulations differs between the two runs)."""
