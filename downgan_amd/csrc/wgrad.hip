@@ -923,243 +923,6 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
   return wg_det_end(a, plan, lo, span, st);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// The same workgroup tile (128 x 128 x 3 taps, 32-pixel steps, DMA-fed LDS ring) on v_mfma_f32_16x16x32_bf16 with EIGHT waves in ONE
-// workgroup per CU.  Why: on random data the chip holds a lower clock under the 32x32x16 shape (PMC, round 2: 1.76-1.81 GHz in
-// wg3w against 1.97-2.06 in the 16x16x32 conv kernel; MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.15x for the 16x16x32 loop
-// at equal cycles per flop).  At wg3w's wave tile (128 x 32 x 3 = 192 accumulator registers) the 16x16x32 fragments need 24 more
-// registers than the 256 of a two-workgroups-per-CU kernel have, so the wave tile is halved (64 x 32 x 3 = 96 accumulators) and the
-// waves doubled: wave w = adjoint half w >> 2, input-channel quarter w & 3.  Same bytes per flop from L2, fewer LDS fragment reads
-// per MFMA cycle (20 transposing reads per 24 MFMAs), 2-3 DMA pieces per wave and step instead of 4-5.  A workgroup runs hundreds
-// of steps, so the second workgroup's cover of prologue / epilogue is not missed.
-// LDS rows are 256 B; the 32-byte group index (16 channels) is XOR-swizzled on the DMA's SOURCE side so that the 8 rows a half
-// wave's transposing read touches (2 K-groups x 4 rows) fall into 8 different 32-byte bank groups:
-//   adjoint tile / stride-1 input tile: key(row) = (row & 3) | ((row >> 3) & 1) << 2        (rows 8g + q [+ tap])
-//   stride-2 input tile:                key(row) = ((row >> 1) & 3) | ((row >> 4) & 1) << 2  (rows 16g + 2q + tap)
-template <bool S2>
-__global__ __launch_bounds__(512, 1) void wg3x_kernel(const WGArgs a) {
-  constexpr int BCO = 128, BCI = 128, KP = 32;
-  constexpr int XROWS = S2 ? 65 : KP + 2;                      // input pixels under 32 output pixels
-  constexpr int NXPC = S2 ? 17 : 9, XALLOC = 4 * NXPC;         // x tile in 4-row DMA pieces (surplus rows: zero-filled, never read)
-  constexpr int ROWB = 256, SU_B = KP * ROWB, SX_B = XALLOC * ROWB, BUFB = SU_B + SX_B, NBUF = 3;
-  extern __shared__ __attribute__((aligned(16))) unsigned char wgx_dsm[];            // NBUF * BUFB
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
-  const unsigned lin = gridDim.x <= 72 ? xcd_remap(lin0, gridDim.x * gridDim.y) : lin0;
-  const int bx = (int)(lin % gridDim.x), by = (int)(lin / gridDim.x);
-  int ci_t = bx % a.nci_t;
-  int trow = (bx / a.nci_t) % 3;
-  int co_t = bx / (a.nci_t * 3);
-  if (a.tri) {                                  // bx = 3 * pair + tap row; pair p = t (t + 1) / 2 + input tile, input tile <= t
-    trow = bx % 3;
-    const int p = bx / 3;
-    co_t = 0;
-    while ((co_t + 1) * (co_t + 2) / 2 <= p) ++co_t;
-    ci_t = p - co_t * (co_t + 1) / 2;
-  }
-  const int co0 = co_t * BCO, ci0 = ci_t * BCI;
-  const int dr = trow - 1;
-  const int pbeg = by * a.ppb;
-  const int pend = min(a.Mpix, pbeg + a.ppb);
-  const int nsteps = (pend - pbeg + KP - 1) / KP;
-  if (nsteps <= 0) return;
-  const char* X = reinterpret_cast<const char*>(a.x);
-  const char* U = reinterpret_cast<const char*>(a.u);
-  const int ch = wave >> 2, cq = wave & 3;                     // adjoint-channel half, input-channel quarter of this wave
-
-  // ---- DMA lane constants: a piece = 4 rows x 256 B; lane -> (row 4p + lane / 16, physical 16-byte chunk lane % 16)
-  const int drow = lane >> 4, pc = lane & 15;
-  auto key_u = [](int row) { return (row & 3) | (((row >> 3) & 1) << 2); };
-  auto key_x = [](int row) { return S2 ? ((row >> 1) & 3) | (((row >> 4) & 1) << 2) : (row & 3) | (((row >> 3) & 1) << 2); };
-  constexpr int NXW = S2 ? 2 : 1;                              // x pieces every wave issues per tile (+ the last piece, in turn)
-  unsigned uoff, xoff[NXW + 1];
-  int xr[NXW + 1];
-  {
-    const int row = 4 * wave + drow, c = pc ^ (key_u(row) << 1), co = co0 + c * 8;
-    if (co >= a.Cout) uoff = WG_OOB_OFF;
-    else if (!a.u_ps) uoff = (unsigned)(((long long)row * a.ldu + co) * 2);
-    else {
-      const int cchunk = co / 8, q = cchunk / a.cps_chunks, cc = cchunk - q * a.cps_chunks;
-      uoff = (unsigned)((((long long)(q >> 1) * (2 * a.Wo) + 2 * row + (q & 1)) * a.ldu + cc * 8) * 2);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j <= NXW; ++j) {
-    const int piece = j < NXW ? wave + 8 * j : NXPC - 1;
-    const int row = 4 * piece + drow, c = pc ^ (key_x(row) << 1), ci = ci0 + c * 8;
-    xr[j] = row;
-    xoff[j] = (row < XROWS && ci < a.Cin) ? (unsigned)(((long long)row * a.ldx + ci) * 2) : WG_OOB_OFF;
-  }
-  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)wgx_dsm));
-  typedef int i32x4w_t __attribute__((ext_vector_type(4)));
-  auto dma = [&](unsigned m0v, unsigned voff, const i32x4w_t& rs) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rs) : "memory");
-  };
-  auto make_rs = [&](const char* base) {
-    const unsigned long long b = (unsigned long long)base;
-    i32x4w_t rs;
-    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
-    rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
-    rs[2] = (int)WG_OOB_OFF;
-    rs[3] = 0x00020000;
-    return rs;
-  };
-  int s_wo = pbeg % a.Wo, s_ho, s_n;
-  { const int t = pbeg / a.Wo; s_ho = t % a.Ho; s_n = t / a.Ho; }
-  auto issue = [&](int buf, int t) {
-    const long long ub = !a.u_ps ? ((long long)(s_n * a.Ho + s_ho) * a.Wo + s_wo) * a.ldu
-                                 : ((long long)(s_n * 2 * a.Ho + 2 * s_ho) * (2 * a.Wo) + 2 * s_wo) * a.ldu;
-    const int hi = (S2 ? 2 * s_ho : s_ho) + dr;
-    const bool row_ok = (unsigned)hi < (unsigned)a.H;
-    const int wi0 = (S2 ? 2 * s_wo : s_wo) - 1;                 // input column of tile row 0
-    const long long xb = ((long long)(s_n * a.H + (row_ok ? hi : 0)) * a.W + wi0) * a.ldx;
-    const i32x4w_t rsU = make_rs(U + ub * 2), rsX = make_rs(X + xb * 2);
-    const unsigned m0b = lds0 + (unsigned)buf * BUFB;
-    dma(m0b + (unsigned)wave * 1024u, uoff, rsU);
-#pragma unroll
-    for (int j = 0; j < NXW; ++j) {
-      const unsigned vo = (row_ok && (unsigned)(wi0 + xr[j]) < (unsigned)a.W) ? xoff[j] : WG_OOB_OFF;
-      dma(m0b + SU_B + (unsigned)(wave + 8 * j) * 1024u, vo, rsX);
-    }
-    if ((t & 7) == wave) {                                      // the last rows (+ zero rows): one wave per step, in turn
-      const unsigned vo = (row_ok && (unsigned)(wi0 + xr[NXW]) < (unsigned)a.W) ? xoff[NXW] : WG_OOB_OFF;
-      dma(m0b + SU_B + (unsigned)(NXPC - 1) * 1024u, vo, rsX);
-    }
-    s_wo += KP;
-    if (s_wo >= a.Wo) { s_wo = 0; if (++s_ho == a.Ho) { s_ho = 0; ++s_n; } }
-  };
-
-  f32x4_t acc[3][4][2];                                        // [tap][adjoint block of 16][input block of 16]
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) acc[s][cb][ib] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // ---- fragment read offsets (bytes inside a buffer).  A transposing read: the 16 lanes of a group address 4 rows (q) x 4
-  // 8-byte column quads (pp) of a 4 x 16 block and lane i16 receives channel i16 of the block for those 4 rows; lane group g =
-  // K-group g (pixels 8g .. 8g + 7 of the step: two reads, rows +0 and +4).
-  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, l15 = lane & 15;
-  const int ru = 8 * g + q;                                    // adjoint row (key(row + 4) == key(row): the hi read is 4 rows further)
-  const int bu = ru * ROWB + (((ch * 4) ^ key_u(ru)) << 5) + 8 * pp;                 // block cb at bu ^ (cb << 5)
-  int bx_lo[3], bx_hi[3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int r0 = S2 ? 2 * (8 * g + q) + s : 8 * g + q + s, r1 = r0 + (S2 ? 8 : 4);
-    bx_lo[s] = SU_B + r0 * ROWB + (((cq * 2) ^ key_x(r0)) << 5) + 8 * pp;          // block ib at b ^ (ib << 5)
-    bx_hi[s] = SU_B + r1 * ROWB + (((cq * 2) ^ key_x(r1)) << 5) + 8 * pp;
-  }
-  // bias gradient on the side (waves of input quarter 0 in the centre-tap-row / first-input-tile workgroups): a lane's 8 values
-  // of an adjoint fragment belong to one channel
-  float* const db_out = a.tri ? (a.dbk[co_t] ? WG_DET_PTR(a, a.dbk[co_t], by) : nullptr)
-                              : (a.db ? WG_DET_DB(a, by) + co0 : nullptr);
-  const bool do_db = db_out != nullptr && trow == 1 && ci_t == 0 && cq == 0;
-  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
-
-  issue(0, 0);
-  if (nsteps > 1) issue(1, 1);
-  // every wave has NXW + 1 (or + 2) pieces per tile in flight: "at most NXW + 1 outstanding" = everything older than the newest tile landed
-  auto wait_older = [&](bool newest_in_flight) {
-    if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXW + 1) : "memory");
-  };
-  wait_older(nsteps > 1);
-  __syncthreads();
-  int cur = 0;
-  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-  for (int ks = 0; ks < nsteps; ++ks) {
-    const bool ahead = ks + 2 < nsteps;
-    int nb = cur + 2; if (nb >= NBUF) nb -= NBUF;
-    if (ahead) issue(nb, ks + 2);            // buffer (ks + 2) % 3 was last read in step ks - 1, behind that step's barrier
-    const unsigned char* sb = wgx_dsm + cur * BUFB;
-    auto frag = [&](int off_lo, int off_hi) {
-      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sb + off_lo));
-      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sb + off_hi));
-      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      return __builtin_bit_cast(bf16x8_t, v);
-    };
-    bf16x8_t fa[4], fb[2], fbn[2];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) fa[cb] = frag(bu ^ (cb << 5), (bu ^ (cb << 5)) + 4 * ROWB);
-    fb[0] = frag(bx_lo[0], bx_hi[0]); fb[1] = frag(bx_lo[0] ^ 32, bx_hi[0] ^ 32);
-    if (do_db) {
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        const u32x4w_t w4 = __builtin_bit_cast(u32x4w_t, fa[cb]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dbacc[cb] += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (s < 2) { fbn[0] = frag(bx_lo[s + 1], bx_hi[s + 1]); fbn[1] = frag(bx_lo[s + 1] ^ 32, bx_hi[s + 1] ^ 32); }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
-          acc[s][cb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cb], fb[ib], acc[s][cb][ib], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s < 2) { fb[0] = fbn[0]; fb[1] = fbn[1]; }
-    }
-    wait_older(ahead);
-    __syncthreads();
-    if (++cur == NBUF) cur = 0;
-  }
-
-  if (do_db) {      // the four K-groups of a channel each add their partial sum
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-      if (co0 + 64 * ch + 16 * cb + l15 < a.Cout) atomicAdd(db_out + 64 * ch + 16 * cb + l15, dbacc[cb]);
-  }
-  // epilogue: D[row = adjoint channel 4g + e][col = input channel l15] of every (tap, cb, ib) block; one lane-constant 32-bit
-  // offset, everything else of an element's address is workgroup-uniform
-  const int cin_w = a.tri ? (co_t + 1) * BCI : a.Cin;                  // input channels of the conv these rows belong to
-  const int cow0 = a.tri ? 0 : co0;                                    // first gradient row of this tile inside that conv
-  float* const dw_out = WG_DET_PTR(a, a.tri ? a.dwk[co_t] : a.dw, by);
-  const long long ldw = 9ll * cin_w;
-  const int cil = ci0 + 32 * cq + l15;
-  const unsigned lane_off = (unsigned)((((long long)cow0 + 64 * ch + 4 * g) * ldw + cil) * 4);
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int tap = trow * 3 + s;
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int cor = 16 * cb + e;                                   // + co0 + 64 ch + 4 g
-          char* const base = reinterpret_cast<char*>(dw_out) + ((long long)cor * ldw + (long long)tap * cin_w + 16 * ib) * 4;
-          if (cil + 16 * ib < cin_w && co0 + 64 * ch + 4 * g + cor < a.Cout) atomicAdd(reinterpret_cast<float*>(base + lane_off), acc[s][cb][ib][e]);
-        }
-  }
-}
-
-template <bool S2>
-static int wg3x_launch(WGArgs& a, hipStream_t st) {
-  constexpr int BCO = 128, BCI = 128;
-  const int nco_t = (a.Cout + BCO - 1) / BCO;
-  a.nci_t = (a.Cin + BCI - 1) / BCI;
-  const int npairs = a.tri ? nco_t * (nco_t + 1) / 2 : nco_t * a.nci_t;
-  const int ntiles = 3 * npairs;
-  const double flops = 2.0 * 9 * BCO * (double)BCI * npairs * a.Mpix;
-  const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
-  static const int tb_env = getenv("DG_WG_TBX") ? atoi(getenv("DG_WG_TBX")) : 768;   // 3 rounds of 256 slots (1 per CU)
-  int splits = wg_pick_splits(ntiles, tb_env, cap, a.Mpix, &a.ppb);
-  DetPlan plan; float* lo = nullptr; long long span = 0;
-  const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
-  if (granted < 0) return DG_ERR_LAUNCH;
-  if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb);
-  constexpr int lds = 3 * (32 * 256 + (S2 ? 68 : 36) * 256);
-  DG_SET_MAX_LDS_ONCE((&wg3x_kernel<S2>), lds);
-  hipLaunchKernelGGL((wg3x_kernel<S2>), dim3(ntiles, splits), dim3(512), lds, st, a);
-  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
-  return wg_det_end(a, plan, lo, span, st);
-}
-
 extern "C" int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, int64_t rows_inner, int64_t ld, int C,
                          float* db, void* stream);
 
@@ -1210,9 +973,6 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
     if (rc) return rc;
   }
   a.db = fused_db ? db : nullptr;
-  static const bool use_x = getenv("DG_WG_X") != nullptr;         // A/B: the 16x16x32 / eight-wave form of the wide kernel
-  if (use_x && wide_s1) return wg3x_launch<false>(a, st);
-  if (use_x && wide_s2 && !rows) return wg3x_launch<true>(a, st);
   if (wide_s1) return wg3w_launch<false>(a, st);
   if (rows) return g->dtype == DG_F32 ? wg3_launch<float>(a, st) : wg3_launch<bf16_t>(a, st);
   if (wide_s2) return wg3w_launch<true>(a, st);
@@ -1244,7 +1004,5 @@ extern "C" int dg_conv3x3_wgrad_dense(const dg_conv_geom* g, int nconv, const vo
   a.db = nullptr;
   a.tri = 1;
   for (int k = 0; k < nconv; ++k) { a.dwk[k] = dw[k]; a.dbk[k] = db ? db[k] : nullptr; }
-  static const bool use_x = getenv("DG_WG_X") != nullptr;
-  if (use_x) return wg3x_launch<false>(a, reinterpret_cast<hipStream_t>(stream));
   return wg3w_launch<false>(a, reinterpret_cast<hipStream_t>(stream));
 }
