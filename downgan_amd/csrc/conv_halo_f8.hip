@@ -79,8 +79,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
   auto load_patch = [&](int vcb) {
     const int plane = plane_of(vcb), cb = vcb - plane * ncbr;
     const int ppy = plane >> 1, ppx = plane & 1;
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
-    __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc((void*)(XSb + cb * 4), 0, (int)DG_OOB_OFF, 0x00020000);
+    // (bases made provably workgroup-uniform: otherwise each load below sits in its own waterfall loop, see conv_halo.hip)
+    auto uni = [](const void* p) {
+      const unsigned long long b = (unsigned long long)p;
+      return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b));
+    };
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(uni(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(uni(XSb + cb * 4), 0, (int)DG_OOB_OFF, 0x00020000);
     int r0v = r0;
     asm volatile("" : "+v"(r0v));
 #pragma unroll
