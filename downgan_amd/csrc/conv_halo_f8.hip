@@ -14,8 +14,10 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 // reads byte g.  Output: bf16 through the common epilogue (activations, masks, bit masks as in the bf16 kernel).
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 
-template <bool S2, int NW = 4>       // NW = 8: 256-channel tile, two channel halves on one patch (see gg_halo4w_kernel)
+// SEG: a stride-2 data gradient's four parity classes as one launch in (image, class | tile row, tile) order, as in gg_halo4w_kernel.
+template <bool S2, int NW = 4, bool SEG = false>       // NW = 8: 256-channel tile, two channel halves on one patch (see gg_halo4w_kernel)
 __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a, const F8Args f, int tiles_x, int tiles_y) {
+  static_assert(!SEG || (!S2 && NW == 4), "SEG is a mode of the plain four-wave kernel");
   constexpr int EPC = 16, ES = 1;
   constexpr int NT = 64 * NW, RPP = NT / 8;
   constexpr int TH = 16, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW;   // 324 patch rows
@@ -33,12 +35,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
   char* const s_ps = s_ws + 2 * BC * 4;                        // [PROWS] u32: same for the patch pixels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned tile = xcd_remap(blockIdx.x, a.nwg);
+  const unsigned tile = SEG ? blockIdx.x : xcd_remap(blockIdx.x, a.nwg);
   const int tile_c = tile % a.nct;
   unsigned rest = tile / a.nct;
   const int tx0 = (rest % tiles_x) * TW; rest /= tiles_x;
-  const int ty0 = (rest % tiles_y) * TH;
-  const int img = rest / tiles_y;
+  int cls = 0;                                                   // SEG: parity class of this workgroup (order: a.seg, conv_halo.hip)
+  if (SEG && a.seg == 2) { cls = (int)(rest & 3u); rest >>= 2; }
+  const int ty0 = (rest % tiles_y) * TH; rest /= tiles_y;
+  if (SEG && a.seg != 2) { cls = (int)(rest & 3u); rest >>= 2; }
+  const int img = (int)rest;
+  const int ntaps_l = SEG ? (0x4221 >> (4 * cls)) & 15 : a.ntaps;
+  const int tap0_l = SEG ? (0x5310 >> (4 * cls)) & 15 : 0;
   const int c0 = tile_c * BC;
   const int cc = tid & 7, r0 = tid >> 3;          // r0 in [0, RPP)
   const int wq = wave & 3, wh = wave >> 2;        // tile rows 4*wq.., channel half wh (0 unless NW = 8)
@@ -51,9 +58,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
   const int l15 = lane & 15, g = lane >> 4;
   const int ncbr = a.cch / KC;                    // real 128-channel blocks
   const int ncb = S2 ? 4 * ncbr : ncbr;           // (plane, channel block) pairs, plane-major
-  const int nsteps = ncbr * a.ntaps;
+  const int nsteps = ncbr * ntaps_l;
   auto plane_of = [&](int vcb) { return S2 ? (int)(vcb >= ncbr) + (int)(vcb >= 2 * ncbr) + (int)(vcb >= 3 * ncbr) : 0; };
-  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : a.ntaps; };
+  auto ntaps_of = [&](int vcb) { return S2 ? (0x4221 >> (4 * plane_of(vcb))) & 15 : ntaps_l; };
 
   unsigned woff[NWL];                             // DMA piece i of this wave: rows wave*32 + 8i .. +7, lane = (row, physical chunk)
 #pragma unroll
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
     wsoff = (unsigned)(row * ldws);
   }
   auto tap_code = [&](int vcb, int tap) {
-    const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap;
+    const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap0_l + tap;
     return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
   };
   u32x4_t rp[NPL];
@@ -259,23 +266,25 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
     tap = ntap; cb = ncbn;
   }
 #undef F8_FENCE
-  halo_epilogue<bf16_t, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
+  if constexpr (SEG) halo_epilogue<bf16_t, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, cls >> 1, cls & 1);
+  else halo_epilogue<bf16_t, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
 }
 
-template <bool S2, int NW = 4>
+template <bool S2, int NW = 4, bool SEG = false>
 static int gg_launch_halo4w_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st) {
   constexpr int BC = 32 * NW;
   constexpr int LDS_BYTES = 324 * 144 + 2 * BC * 128 + 2 * BC * 4 + 324 * 4;
-  DG_SET_MAX_LDS_ONCE((&gg_halo4w_f8_kernel<S2, NW>), LDS_BYTES);
+  DG_SET_MAX_LDS_ONCE((&gg_halo4w_f8_kernel<S2, NW, SEG>), LDS_BYTES);
   const int tiles_x = (a.Wg + 15) / 16, tiles_y = (a.Hg + 15) / 16;
   a.nct = (unsigned)((a.Nout + BC - 1) / BC);
-  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N);
+  a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N) * (SEG ? 4u : 1u);
   g_last_kinds |= 32;
-  hipLaunchKernelGGL((gg_halo4w_f8_kernel<S2, NW>), dim3(a.nwg), dim3(64 * NW), LDS_BYTES, st, a, f, tiles_x, tiles_y);
+  hipLaunchKernelGGL((gg_halo4w_f8_kernel<S2, NW, SEG>), dim3(a.nwg), dim3(64 * NW), LDS_BYTES, st, a, f, tiles_x, tiles_y);
   return dg_check_launch();
 }
 
 int gg_launch_halo_f8(GGArgs& a, const F8Args& f, int N, bool s2, int nw, hipStream_t st) {
+  if (a.seg) return gg_launch_halo4w_f8<false, 4, true>(a, f, N, st);
   if (!s2) return gg_launch_halo4w_f8<false>(a, f, N, st);
   return nw == 8 ? gg_launch_halo4w_f8<true, 8>(a, f, N, st) : gg_launch_halo4w_f8<true>(a, f, N, st);
 }

@@ -263,6 +263,11 @@ extern "C" int dg_conv3x3_dgrad_f8(const dg_conv_geom* g, const dg_epilogue* ep,
   g_last_kinds = 0;
   int n = dg_conv3x3_plan(g, 1, d);
   if (n < 0) return n;
+  dg_gg_desc ds;
+  if (seg_dgrad_desc(d, n, &ds) && ds.Cred % 128 == 0) {       // stride 2: the four parity classes as one launch (conv_halo_f8.hip, SEG)
+    ds.lds = q->ldxq;
+    return gather_gemm_impl(&ds, ep, q->xq, q->wq, dx, stream, false, q, true);
+  }
   for (int i = 0; i < n; ++i) {
     d[i].lds = q->ldxq;
     int rc = gather_gemm_impl(&d[i], ep, q->xq, q->wq, dx, stream, false, q);
