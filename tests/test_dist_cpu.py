@@ -25,20 +25,20 @@ def _build(B, dist=None, global_b=None):
     return eng, ops
 
 
-def _data(lo, hi):
-    coarse, fine = synthetic.tiles(2, CFG["cin"], CFG["S"])
-    alpha = synthetic.alpha(2, 0)
+def _data(lo, hi, gb=2):
+    coarse, fine = synthetic.tiles(gb, CFG["cin"], CFG["S"])
+    alpha = synthetic.alpha(gb, 0)
     tc, tf = torch.from_numpy(coarse[lo:hi]), torch.from_numpy(fine[lo:hi])
     return nchw_to_nhwc_padded(tc, 16, torch.float32), nchw_to_nhwc_padded(tf, 16, torch.float32), torch.from_numpy(alpha[lo:hi])
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, bucket_elems=64 * 1024 * 1024):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     from downgan_amd.dist import Dist
-    dist = Dist("gloo")
-    eng, _ = _build(1, dist, global_b=2)
-    xc, xf, alpha = _data(rank, rank + 1)
+    dist = Dist("gloo", bucket_elems=bucket_elems)
+    eng, _ = _build(1, dist, global_b=world)
+    xc, xf, alpha = _data(rank, rank + 1, world)
     metrics = eng.metrics_pass(xc, xf)          # before the update: global-batch min/max (all-reduce MIN/MAX) and means
     ran_g = eng.train_step(xc, xf, alpha)       # step 0: critic + generator update
     assert eng.G.P._pending is not None         # the generator update is parked behind the next critic iteration's real pass
@@ -49,20 +49,21 @@ def _worker(rank, world, port, outdir):
     dist.barrier()
 
 
-def test_two_ranks_equal_single_process():
+@pytest.mark.parametrize("world,bucket_elems", [(2, 64 * 1024 * 1024), (4, 100_000)])      # 4 ranks: the 1.1 M-float buffer in 12 buckets
+def test_ranks_equal_single_process(world, bucket_elems):
     torch.set_num_threads(4)
-    eng, _ = _build(2)
-    xc, xf, alpha = _data(0, 2)
+    eng, _ = _build(world)
+    xc, xf, alpha = _data(0, world, world)
     ref_metrics = eng.metrics_pass(xc, xf)
     ran_g = eng.train_step(xc, xf, alpha)
     eng.train_step(xc, xf, alpha)
     ref_scal = eng.read_scalars(ran_g)
     ref_c, ref_g = eng.C.state_dict(), eng.G.state_dict()
     with tempfile.TemporaryDirectory() as d:
-        port = 29600 + os.getpid() % 200
-        mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
+        port = 29600 + os.getpid() % 200 + world
+        mp.spawn(_worker, args=(world, port, d, bucket_elems), nprocs=world, join=True)
         r0 = torch.load(os.path.join(d, "r0.pt"))
-        r1 = torch.load(os.path.join(d, "r1.pt"))
+        r1 = torch.load(os.path.join(d, f"r{world - 1}.pt"))
     for k in ref_c:
         assert torch.equal(r0["C"][k], r1["C"][k]), k                       # replicas stay identical
         # two Adam steps: an entry whose gradient is rounding noise (|g| ~ eps) moves by up to lr per step in either
