@@ -226,6 +226,9 @@ class NativeCritic:
         # below work on the first B.  Needs the bit masks (the tangent pass reads a row range of them), the fused FC1 gradient and,
         # for the memory (3 x 40 GB of activations + adjoints at cfg2), no fp8 copies.
         self.stacked = bool(stacked) and use_bits and not self.f8 and 3 * batch <= 128 and os.environ.get("DG_NO_FC1_FUSED") is None
+        # stacked = k > 1 (an int): only layers k - 1 ... 7 run as one batch of 3B; layers below it -- the ones that read or write the
+        # first layer's 25-GB-at-3B tensors, which LOSE 5-8 % when stacked -- keep one launch per pass into row ranges of the same buffers
+        self.stack_from = (int(stacked) - 1 if (stacked is not True and int(stacked) > 1) else 0) if self.stacked else 0
         cap = 3 * batch if self.stacked else batch
         self.cap = cap
         full = lambda cv: (cap,) + tuple(o.out_shape(cv))[1:]
@@ -462,8 +465,13 @@ class NativeCritic:
             self._cv_cache = {}
         cur = x3
         for l, cv in enumerate(self._cvn(3 * B)):
-            o.conv_fwd(cv, cur, P.w(f"features.{2 * l}.weight"), self._acts_all[l],
-                       bias=P.master("features.0.bias") if l == 0 else None, act=C_SLOPE, out_bits=self._bits_all[l])
+            w, bias = P.w(f"features.{2 * l}.weight"), P.master("features.0.bias") if l == 0 else None
+            if l < self.stack_from:           # one launch per pass (real | fake | x-hat) on row ranges of the stacked buffers
+                for p in range(3):
+                    r = slice(p * B, (p + 1) * B)
+                    o.conv_fwd(self.convs[l], cur[r], w, self._acts_all[l][r], bias=bias, act=C_SLOPE, out_bits=self._bits_all[l][r])
+            else:
+                o.conv_fwd(cv, cur, w, self._acts_all[l], bias=bias, act=C_SLOPE, out_bits=self._bits_all[l])
             cur = self._acts_all[l]
         y7 = self._acts_all[7].view(3 * B, self.fc_k)
         self._h1pre_all.zero_()
@@ -499,8 +507,19 @@ class NativeCritic:
         for l in range(7, -1, -1):
             name = f"features.{2 * l}.weight"
             xin = self._acts_all[l - 1] if l > 0 else x3
-            o.conv_wgrad(cv2[l], xin[w2], self._us_all[l][w2], P.grad(name).reshape(-1), db=P.grad("features.0.bias") if l == 0 else None)
-            if l > 0:
+            db = P.grad("features.0.bias") if l == 0 else None
+            per_pass = l < self.stack_from
+            if per_pass:
+                for p in range(2):
+                    r = slice(p * B, (p + 1) * B)
+                    o.conv_wgrad(cv1[l], xin[r], self._us_all[l][r], P.grad(name).reshape(-1), db=db)
+            else:
+                o.conv_wgrad(cv2[l], xin[w2], self._us_all[l][w2], P.grad(name).reshape(-1), db=db)
+            if l > 0 and per_pass:
+                for p in range(3):
+                    r = slice(p * B, (p + 1) * B)
+                    o.conv_dgrad(cv1[l], self._us_all[l][r], P.wd(name), self._us_all[l - 1][r], mask_bits=self._bits_all[l - 1][r], mask_slope=C_SLOPE)
+            elif l > 0:
                 o.conv_dgrad(cv3[l], self._us_all[l], P.wd(name), self._us_all[l - 1], mask_bits=self._bits_all[l - 1], mask_slope=C_SLOPE)
             else:
                 o.conv_dgrad(cv1[0], self._us_all[0][2 * B:], P.wd(name), dx)
@@ -806,9 +825,10 @@ class TrainEngine:
             os.environ.get(k) is not None for k in ("DG_NO_COMPACT2", "DG_WG_NOIM2COL", "DG_GG_NOIM2COL"))
         # OPT-IN (stacked=True / DG_STACKED=1): measured +0.4-0.6 % per step at cfg2 for +77 GiB of HBM, and the
         # data-parallel overlap of the generator's gradient exchange with the real-batch pass goes away
-        if stacked is None:
-            stacked = os.environ.get("DG_STACKED") is not None
-        stacked = stacked and compact2 and self._fits_stacked(ops, filters, batch, coarse_side, fine, num_res_blocks)
+        if stacked is None:                 # DG_STACKED=1: every layer; DG_STACKED=k > 1: layers k - 1 .. 7 only (NativeCritic.stack_from)
+            env = os.environ.get("DG_STACKED")
+            stacked = (int(env) if env.isdigit() and int(env) > 1 else True) if env is not None else False
+        stacked = stacked if (stacked and compact2 and self._fits_stacked(ops, filters, batch, coarse_side, fine, num_res_blocks)) else False
         self.C = NativeCritic(ops, filters, fine, n_predictands, batch, stacked=stacked)
         assert self.C.c_pad[0] == self.G.np_p
         o = ops

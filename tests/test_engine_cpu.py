@@ -131,8 +131,8 @@ def test_state_dict_roundtrip():
         assert torch.equal(sd[k], torch.from_numpy(v)), k
 
 
-@pytest.mark.parametrize("fs", [False, True])
-def test_stacked_critic_passes_equal_separate_passes(fs):
+@pytest.mark.parametrize("fs,mode", [(False, True), (True, True), (False, 3)])      # 3: layers 2..7 stacked, the first two per pass
+def test_stacked_critic_passes_equal_separate_passes(fs, mode):
     """TrainEngine(stacked=True) (opt-in: the real, generated and interpolated batch through the critic as ONE batch of 3B,
     wasserstein.py:37, 38, 97 / :52 / :100-106) gives the scalars and critic gradients of the three separate passes; it needs the 128-wide critic
     (bit masks) and the compact 2-channel inputs, so this runs at F = 128 on a 4 x 4 -> 32 x 32 tile, batch 2."""
@@ -142,8 +142,8 @@ def test_stacked_critic_passes_equal_separate_passes(fs):
     for stacked in (True, False):
         ops = EmuOps("f32")
         B, S, F_ = 2, 4, 128
-        eng = (TrainEngineFS if fs else TrainEngine)(ops, S, F_, 2, B, HyperParams(batch_size=B), num_res_blocks=1, stacked=stacked)
-        assert eng.stacked == stacked and eng.compact2
+        eng = (TrainEngineFS if fs else TrainEngine)(ops, S, F_, 2, B, HyperParams(batch_size=B), num_res_blocks=1, stacked=mode if stacked else False)
+        assert eng.stacked == stacked and eng.compact2 and eng.C.stack_from == (2 if (stacked and mode == 3) else 0)
         eng.G.load_state_dict(synthetic.generator_params(F_, 2, 2, 1))
         eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
         coarse, fine = synthetic.tiles(B, 2, S)
