@@ -258,12 +258,15 @@ def test_fp32_two_steps_with_updates_full_tile():
     n1 = eng.read_scalars(False)
     del eng
     torch.cuda.empty_cache()
-    # ---- fp32 oracle
+    # ---- fp32 oracle (its step-0 generator gradients and updated generator are kept for the light float64 run below)
     o32 = ref_step.OracleTrainer(pg, pc, ref_step.HP(batch_size=B), num_res_blocks=NRB)
-    r0 = o32.train_step(tc, tf, a0)
+    r0, _ = o32.critic_iteration(tc, tf, a0)
+    rg, gg32 = o32.generator_iteration(tc, tf)
+    r0.update(rg)
     for k in CK + ("g_loss", "content_loss"):
         assert rel(n0[k], r0[k]) < 1e-4, (0, k, n0[k], r0[k])
     r1 = critic_scalars(o32, tc, tf, a1)
+    pg32_after = {k: v.detach().clone() for k, v in o32.PG.items()}
     del o32
     # ---- (a) the oracle's update rule and forward on the NATIVE gradients
     oN = ref_step.OracleTrainer(pg, pc, ref_step.HP(batch_size=B), num_res_blocks=NRB)
@@ -276,12 +279,27 @@ def test_fp32_two_steps_with_updates_full_tile():
     rN = critic_scalars(oN, tc, tf, a1)
     del oN
     own = {k: rel(n1[k], rN[k]) for k in CK}
-    # ---- (b) float64 oracle, the same two steps
+    # ---- (b) float64 oracle, the same two steps.  Routine run: the CRITIC in float64 -- its gradients are where fp32 loses digits
+    # (real / fake terms cancel) -- on the fp32 oracle's generator (G(coarse) of step 0 and the updated generator of step 1 cast to
+    # float64: generator gradients carry no cancellation, and float64 generator convolutions are two thirds of the cost).
+    # DG_TEST_F64_FULL=1: the generator in float64 too (the run recorded in profiles/fp32_two_step_cfg2.json; +2 CPU-minutes).
     d = torch.float64
+    full = os.environ.get("DG_TEST_F64_FULL") is not None
     o64 = ref_step.OracleTrainer({k: v.to(d) for k, v in pg.items()}, {k: v.to(d) for k, v in pc.items()},
                                  ref_step.HP(batch_size=B), num_res_blocks=NRB)
-    _, cg64 = o64.critic_iteration(tc.to(d), tf.to(d), a0.to(d))
-    _, gg64 = o64.generator_iteration(tc.to(d), tf.to(d))
+    if full:
+        _, cg64 = o64.critic_iteration(tc.to(d), tf.to(d), a0.to(d))
+        _, gg64 = o64.generator_iteration(tc.to(d), tf.to(d))
+    else:
+        with torch.no_grad():
+            fake0 = ref_step.generator_forward(pg, tc, NRB).double()
+        o64.G = lambda x: fake0
+        _, cg64 = o64.critic_iteration(tc.to(d), tf.to(d), a0.to(d))
+        with torch.no_grad():
+            fake1 = ref_step.generator_forward(pg32_after, tc, NRB).double()
+        o64.G = lambda x: fake1
+        o64.PG = {k: v.to(d) for k, v in pg32_after.items()}
+        gg64 = gg32                               # (sign agreement of G's first move: against the fp32 oracle)
     q1 = critic_scalars(o64, tc.to(d), tf.to(d), a1.to(d))
     bracket = {k: {"native": n1[k], "oracle_f32": r1[k], "oracle_f64": q1[k], "oracle_rule_on_native_gradients": rN[k],
                    "rel_native_vs_f64": rel(n1[k], q1[k]), "rel_f32_vs_f64": rel(r1[k], q1[k]), "rel_native_vs_f32": rel(n1[k], r1[k]),
@@ -295,7 +313,7 @@ def test_fp32_two_steps_with_updates_full_tile():
     worst = sorted(signs.items(), key=lambda kv: kv[1][0])[:8]
     _dump("fp32_two_step_cfg2.json",
           {"what": "step-1 scalars (after one critic + one generator Adam update) at B=1, 2ch 128->1024, F=128, 16 RRDBs: native fp32-parity mode, "
-                   "the fp32 oracle, the float64 oracle, and the fp32 oracle's update rule + forward applied to the NATIVE step-0 gradients; "
+                   "the fp32 oracle, the float64 oracle (generator in float64 too: " + str(full) + "), and the fp32 oracle's update rule + forward applied to the NATIVE step-0 gradients; "
                    "sign_agreement = share of entries (weighted by |g_f64|, unweighted) whose first Adam move has the float64 oracle's sign",
            "step0_rel_native_vs_f32": {k: rel(n0[k], r0[k]) for k in CK + ("g_loss", "content_loss")},
            "step1": bracket, "sign_agreement_worst": {k: {"weighted": v[0], "unweighted": v[1]} for k, v in worst},
