@@ -500,8 +500,6 @@ static int gg_launch_im2col_t(GGArgs& a, hipStream_t st) {
   }
   const int slots = 256 * occ;
   if (tiles >= 8 * slots) tpb = (tiles + slots - 1) / slots;
-  static const int tpb_env = getenv("DG_GG_IM2COL_TPB") ? atoi(getenv("DG_GG_IM2COL_TPB")) : 0;
-  if (tpb_env > 0) tpb = tpb_env;
   dim3 grid((tiles + tpb - 1) / tpb, (a.Nout + 127) / 128);
   g_last_kinds |= 16;
   if (lean) hipLaunchKernelGGL((gg_im2col_kernel<T, true>), grid, dim3(256), 0, st, a, tpb);

@@ -229,9 +229,6 @@ extern "C" int dg_sumsq_rows(int dtype, const void* g, int B, int64_t per_img, f
   const int epc = dtype == DG_F32 ? 4 : 8;
   long long nb = (per_img / epc + 256 * 8 - 1) / (256 * 8);
   if (nb > 512) nb = 512;
-  const char* env_nb = getenv("DG_COLSUM_NB");
-  if (env_nb && atoi(env_nb) > 0 && atoi(env_nb) < nb) nb = atoi(env_nb);
-  const bool u16 = getenv("DG_COLSUM_U16") != nullptr;
   if (nb < 1) nb = 1;
   if (dtype != DG_F32 && dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
   DetPlan plan;

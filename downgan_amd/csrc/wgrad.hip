@@ -417,18 +417,15 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   const int nco_t = (a.Cout + bco - 1) / bco;
   a.nci_t = (a.Cin + bci - 1) / bci;
   const int ntiles = nco_t * 9 * a.nci_t;
-  static const int target_blocks = getenv("DG_WG_BLOCKS") ? atoi(getenv("DG_WG_BLOCKS")) : 0;   // 0: whole rounds of the resident slots
   // every workgroup ends with a 64-KB (tile) atomic accumulate at ~1.3 TB/s chip-wide: cap the workgroup count so
   // that this traffic stays below ~1/4 of the MFMA time (estimated at 600 TFLOP/s), but keep >= 512 workgroups
   const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
   const long long cap = (long long)(flops * 5.4e-4 / (bco * bci * 4.0));
   static const bool no_rowstep = getenv("DG_WG_GENERIC") != nullptr;
   const bool rs = !no_rowstep && a.Wo % 32 == 0;
-  // 64-pixel K-steps halve the barrier count but also the resident workgroups (LDS): measured equal to 32-pixel
-  // steps, so they are opt-in.  256x128 / 128x256 tiles (each wave 128x64, 2 workgroups per CU, 25 % fewer staged bytes
-  // per flop) were measured 8-20 % SLOWER than 128x128 with 3 workgroups per CU and are not built.
-  static const bool want_kp64 = getenv("DG_WG_KP64") != nullptr;
-  const bool kp64 = rs && want_kp64 && a.Wo % 64 == 0 && sizeof(T) == 2;                 // (ppb is a multiple of 64)
+  // 64-pixel K-steps (half the barriers, half the resident workgroups) were measured equal to 32-pixel steps, and
+  // 256x128 / 128x256 tiles (2 workgroups per CU, 25 % fewer staged bytes per flop) 8-20 % SLOWER than 128x128 with 3
+  // workgroups per CU: neither is built.
   constexpr int PADE = sizeof(T) == 2 ? 32 : 0;
   DetPlan plan; float* lo = nullptr; long long span = 0;
 #define WG_LAUNCH1(BCO, BCI, RS, KPV)                                                                 \
@@ -439,7 +436,7 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
     int occ = occ_cache.load(std::memory_order_relaxed);                                              \
     if (!occ) { occ = wg_resident(wg_kernel<T, BCO, BCI, RS, KPV>, lds); occ_cache.store(occ, std::memory_order_relaxed); } \
     /* 3 rounds of the resident slots, 2 when more than 3 workgroups share a CU */                    \
-    const long long target = target_blocks ? target_blocks : (long long)(occ > 3 ? 2 : 3) * 256 * occ; \
+    const long long target = (long long)(occ > 3 ? 2 : 3) * 256 * occ;                                \
     int splits = wg_pick_splits(ntiles, target, cap, a.Mpix, &a.ppb);                                 \
     const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);                               \
     if (granted < 0) return DG_ERR_LAUNCH;                                                            \
@@ -449,8 +446,7 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   } while (0)
 #define WG_LAUNCH(BCO, BCI)                                                                           \
   do {                                                                                                \
-    if (kp64) { if constexpr (sizeof(T) == 2) WG_LAUNCH1(BCO, BCI, true, 64); }                       \
-    else if (rs) WG_LAUNCH1(BCO, BCI, true, 32);                                                      \
+    if (rs) WG_LAUNCH1(BCO, BCI, true, 32);                                                           \
     else WG_LAUNCH1(BCO, BCI, false, 32);                                                             \
   } while (0)
   if (big_co && big_ci) WG_LAUNCH(128, 128);
@@ -910,8 +906,7 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
   const int ntiles = 3 * npairs;
   const double flops = 2.0 * 9 * BCO * (double)BCI * npairs * a.Mpix;
   const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // same atomics-traffic budget as wg_launch
-  static const int tb_env = getenv("DG_WG_TB") ? atoi(getenv("DG_WG_TB")) : 1536;
-  int splits = wg_pick_splits(ntiles, tb_env, cap, a.Mpix, &a.ppb);                 // 3 rounds of 512 slots (2 per CU)
+  int splits = wg_pick_splits(ntiles, 1536, cap, a.Mpix, &a.ppb);                   // 3 rounds of 512 slots (2 per CU)
   DetPlan plan; float* lo = nullptr; long long span = 0;
   const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
   if (granted < 0) return DG_ERR_LAUNCH;
