@@ -37,6 +37,8 @@ def timeit(fn, reps):
 
 
 def main():
+    import os
+    skip_miopen = os.environ.get("LIB_CEILING_NO_MIOPEN") == "1"
     dev = torch.device("cuda:0")
     from downgan_amd.ops import Conv, HipOps
     ops = HipOps("bf16")
@@ -55,11 +57,22 @@ def main():
             a, b = mk(M, K), mk(K, Co)
             ms = timeit(lambda: torch.matmul(a, b), 10)
             row[f"hipblaslt_{data}_tflops"] = round(flops / ms / 1e9, 1)
+            # the same GEMM in fp8 (e4m3, per-tensor scales) where this torch build offers it: the ceiling of the MXFP8 path
+            try:
+                a8, b8 = a.to(torch.float8_e4m3fn), b.t().contiguous().to(torch.float8_e4m3fn)
+                one = torch.ones((), device=dev, dtype=torch.float32)
+                ms = timeit(lambda: torch._scaled_mm(a8, b8.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16), 10)
+                row[f"hipblaslt_fp8_{data}_tflops"] = round(flops / ms / 1e9, 1)
+                del a8, b8
+            except Exception as e:  # noqa: BLE001
+                row[f"hipblaslt_fp8_{data}_tflops"] = f"unavailable: {type(e).__name__}: {str(e)[:80]}"
             del a, b
             # MIOpen (what the reference's torch.nn.Conv2d runs on this GPU), channels_last bf16
             x = mk(B, Ci, H, H).contiguous(memory_format=torch.channels_last)
             w = (mk(Co, Ci, 3, 3) * 0.05).contiguous(memory_format=torch.channels_last)
             try:
+                if skip_miopen:
+                    raise RuntimeError("skipped")
                 ms = timeit(lambda: F.conv2d(x, w, None, stride=s, padding=1), 10)
                 row[f"miopen_{data}_tflops"] = round(flops / ms / 1e9, 1)
             except Exception as e:  # noqa: BLE001
@@ -67,6 +80,8 @@ def main():
             # backward of the same layer through MIOpen (data + weight gradient in one call)
             dy = mk(B, Co, Ho, Ho).contiguous(memory_format=torch.channels_last)
             try:
+                if skip_miopen:
+                    raise RuntimeError("skipped")
                 ms = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
                                                                         [True, True, False]), 5)
                 row[f"miopen_bwd_{data}_tflops"] = round(2 * flops / ms / 1e9, 1)
