@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
     ap.add_argument("--layers", default="", help="comma-separated substrings of layer names to run")
+    ap.add_argument("--net", default="", help='layer tag ("C" makes the wide layers eligible for the fp8 kernels with --dtype fp8)')
     ap.add_argument("--nscale", type=int, default=1, help="multiply every layer's batch (the table uses small batches)")
     args = ap.parse_args()
     o = HipOps(args.dtype)
@@ -38,7 +39,7 @@ def main():
         N *= args.nscale
         if args.layers and not any(k in name for k in args.layers.split(',')):
             continue
-        cv = Conv(N, H, H, ci, co, st, ps, cin_real=(2 if ci == 16 and st == 1 else 0))
+        cv = Conv(N, H, H, ci, co, st, ps, cin_real=(2 if ci == 16 and st == 1 else 0), net=args.net)
         x = torch.randn(N, H, H, ci, generator=g).to(o.tdtype).cuda()
         w = (torch.randn(co * 9 * ci, generator=g) * 0.05).to(o.tdtype).cuda()
         y = o.zeros(*o.out_shape(cv))
