@@ -126,30 +126,52 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
     const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap0_l + tap;
     return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
   };
+  // Patch addressing.  Thread (r0, cc) stages chunk cc of patch pixels r0 + RPP*i, i < NPL; pixel (py, px) of the patch lies at
+  // O + py*rstep + px*cstep from the block's base, and RPP = K1*PW + K2, so chunk i sits at off0 + i*A + w_i*Bd with
+  // w_i = (px0 + i*K2) / PW wraps of the column.  off0, the w_i (4 bits each) and the "outside the image / patch" bits are
+  // computed ONCE; a patch load then costs five VALU operations per chunk instead of re-deriving (py, px), the bounds and the
+  // offset (~15, on a staging path that is issue-bound: -3...-9 % per launch).  The parity plane (S2) / channel quarter (PS) of a
+  // block only moves the uniform base.
+  constexpr int K1 = RPP / PW, K2 = RPP % PW;
+  const int p_rstep = (S2 ? 2 : PS ? 4 : 1) * a.Ws * a.ldx * ES, p_cstep = ((S2 || PS) ? 2 : 1) * a.ldx * ES;
+  const int p_A = K1 * p_rstep + K2 * p_cstep, p_Bd = p_rstep - PW * p_cstep;
+  unsigned p_off0, p_wlo = 0, p_whb = 0;           // p_whb: w_8.. in bits 0-15, invalid bits of chunk i at bit 16 + i
+  {
+    const int py0 = r0 / PW, px0 = r0 - py0 * PW;
+    const int o_rows = S2 ? 2 * (ty0 - 1) - sy_base : PS ? 4 * (ty0 - 1 - sy_base) : ty0 - 1 - sy_base;      // in rows of Ws pixels
+    const int o_cols = (S2 || PS) ? 2 * (tx0 - 1) : tx0 - 1;
+    p_off0 = (unsigned)((o_rows * a.Ws + o_cols) * a.ldx * ES + py0 * p_rstep + px0 * p_cstep) + cc * 16;
+    const unsigned hlim = S2 ? (unsigned)a.Hs >> 1 : (unsigned)a.Hs, wlim = S2 ? (unsigned)a.Ws >> 1 : (unsigned)a.Ws;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int w = (px0 + i * K2) / PW;
+      const int py = py0 + i * K1 + w, px = px0 + i * K2 - w * PW;
+      const bool ok = r0 + RPP * i < PROWS && (unsigned)(ty0 - 1 + py) < hlim && (unsigned)(tx0 - 1 + px) < wlim;
+      if (i < 8) p_wlo |= (unsigned)w << (4 * i); else p_whb |= (unsigned)w << (4 * (i - 8));
+      if (!ok) p_whb |= 1u << (16 + i);
+    }
+  }
+  asm volatile("" : "+v"(p_off0), "+v"(p_wlo), "+v"(p_whb));
   u32x4_t rp[NPL];
   auto load_patch = [&](int vcb) {
     const int plane = plane_of(vcb), cb = vcb - plane * ncbr;
     const int ppy = plane >> 1, ppx = plane & 1;
     const int psq = PS ? (cb * KC) / a.cps_src_chunks : 0;                 // channel quarter of this block
     const int psy = psq >> 1, psx = psq & 1;
-    const long long cboff = PS ? (long long)(cb * KC - psq * a.cps_src_chunks) * EPC * ES : (long long)cb * KC * EPC * ES;
+    long long cboff = PS ? (long long)(cb * KC - psq * a.cps_src_chunks) * EPC * ES : (long long)cb * KC * EPC * ES;
+    if (S2) cboff += (long long)(ppy * a.Ws + ppx) * a.ldx * ES;
+    if (PS) cboff += (long long)(psy * 2 * a.Ws + psx) * a.ldx * ES;
     // the descriptor base is workgroup-uniform, but derived from the (plane, channel block) counter the compiler does not prove
     // uniform: without the readfirstlane pair every one of the NPL loads below sits in its own waterfall loop (S2 / PS instances)
     const unsigned long long xbase = (unsigned long long)(Xb + cboff);
     const unsigned long long xuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32)) << 32) |
                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xbase);
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xuni, 0, (int)DG_OOB_OFF, 0x00020000);
-    int r0v = r0;
-    asm volatile("" : "+v"(r0v));
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      const int pr = r0v + RPP * i;
-      const int py = pr / PW, px = pr - py * PW;
-      const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
-      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-      const unsigned off = !ok ? DG_OOB_OFF
-                           : PS ? (unsigned)(((2 * (sy - sy_base) + psy) * (2 * a.Ws) + 2 * sx + psx) * a.ldx * ES) + cc * 16
-                                : (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16;
+      const int w = (int)__builtin_amdgcn_ubfe(i < 8 ? p_wlo : p_whb, i < 8 ? 4 * i : 4 * (i - 8), 4);
+      const unsigned bad = (unsigned)__builtin_amdgcn_sbfe((int)p_whb, 16 + i, 1);          // all ones when the chunk is outside
+      const unsigned off = ((unsigned)__mul24(w, p_Bd) + p_off0 + (unsigned)(i * p_A)) | bad;  // >= DG_OOB_OFF: the load returns 0
       rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -324,6 +346,8 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
 }
 
 int gg_launch_halo(GGArgs& a, int dtype, int N, bool s2, bool ps, int nw, hipStream_t st) {
+  // the kernel forms patch offsets with 24-bit multiplies of the row step (bytes between patch rows)
+  if ((long long)(ps ? 4 : s2 ? 2 : 1) * a.Ws * a.ldx * (dtype == DG_F32 ? 4 : 2) >= (1ll << 23)) return gg_launch_rows(a, dtype, st);
   if (a.seg) return dtype == DG_BF16 ? gg_launch_halo4w<bf16_t, false, false, 4, true>(a, N, st) : gg_launch_halo4w<float, false, false, 4, true>(a, N, st);
   if (dtype == DG_F32) {
     if (ps) return gg_launch_halo4w<float, false, true>(a, N, st);

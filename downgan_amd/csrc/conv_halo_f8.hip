@@ -81,6 +81,38 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
     const int gt = S2 ? ((0x5310 >> (4 * plane_of(vcb))) & 15) + tap : tap0_l + tap;
     return gt < 8 ? (unsigned)((a.tap_lo >> (8 * gt)) & 0xffull) : (a.tap_hi & 0xffu);
   };
+  // Patch addressing as in gg_halo4w_kernel (conv_halo.hip): chunk i of this thread at off0 + i*A + w_i*Bd, the wrap counts and the
+  // outside-the-image bits computed once, the scale words' offsets likewise.  Only in the eight-wave instance (+2.5-4 %): the
+  // four-wave ones have no registers left for the five values (they spill 8-12 and lose 5-12 %) and re-derive every offset per load.
+  constexpr bool PRE = NW == 8;
+  constexpr int K1 = RPP / PW, K2 = RPP % PW;
+  const int p_rstep = (S2 ? 2 : 1) * a.Ws * a.ldx * ES, p_cstep = (S2 ? 2 : 1) * a.ldx * ES;
+  const int p_A = K1 * p_rstep + K2 * p_cstep, p_Bd = p_rstep - PW * p_cstep;
+  unsigned p_off0 = 0, p_wlo = 0, p_whb = 0;       // p_whb: w_8.. in bits 0-15, invalid bits of chunk i at bit 16 + i
+  unsigned p_soff[NPS];
+  if constexpr (PRE) {
+    const int py0 = r0 / PW, px0 = r0 - py0 * PW;
+    const int o_rows = S2 ? 2 * (ty0 - 1) - sy_base : ty0 - 1 - sy_base;
+    const int o_cols = S2 ? 2 * (tx0 - 1) : tx0 - 1;
+    p_off0 = (unsigned)((o_rows * a.Ws + o_cols) * a.ldx * ES + py0 * p_rstep + px0 * p_cstep) + cc * 16;
+    const unsigned hlim = S2 ? (unsigned)a.Hs >> 1 : (unsigned)a.Hs, wlim = S2 ? (unsigned)a.Ws >> 1 : (unsigned)a.Ws;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int w = (px0 + i * K2) / PW;
+      const int py = py0 + i * K1 + w, px = px0 + i * K2 - w * PW;
+      const bool ok = r0 + RPP * i < PROWS && (unsigned)(ty0 - 1 + py) < hlim && (unsigned)(tx0 - 1 + px) < wlim;
+      if (i < 8) p_wlo |= (unsigned)w << (4 * i); else p_whb |= (unsigned)w << (4 * (i - 8));
+      if (!ok) p_whb |= 1u << (16 + i);
+    }
+#pragma unroll
+    for (int i = 0; i < NPS; ++i) {               // scale words of patch rows tid (and tid + 256)
+      const int pr = tid + NT * i;
+      const int py = pr / PW, px = pr - py * PW;
+      const bool ok = pr < PROWS && (unsigned)(ty0 - 1 + py) < hlim && (unsigned)(tx0 - 1 + px) < wlim;
+      p_soff[i] = ok ? (unsigned)(((o_rows + (S2 ? 2 : 1) * py) * a.Ws + o_cols + (S2 ? 2 : 1) * px) * ldxs) : DG_OOB_OFF;
+    }
+    asm volatile("" : "+v"(p_off0), "+v"(p_wlo), "+v"(p_whb));
+  }
   u32x4_t rp[NPL];
   unsigned rps[NPS];
   auto load_patch = [&](int vcb) {
@@ -92,28 +124,45 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
       return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32) |
                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b));
     };
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(uni(Xb + (long long)cb * KC * EPC * ES), 0, (int)DG_OOB_OFF, 0x00020000);
-    __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(uni(XSb + cb * 4), 0, (int)DG_OOB_OFF, 0x00020000);
-    int r0v = r0;
-    asm volatile("" : "+v"(r0v));
+    const long long pl = (PRE && S2) ? (long long)(ppy * a.Ws + ppx) : 0;   // PRE: the parity plane only moves the uniform bases
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(uni(Xb + (long long)cb * KC * EPC * ES + pl * a.ldx * ES), 0, (int)DG_OOB_OFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc(uni(XSb + cb * 4 + pl * ldxs), 0, (int)DG_OOB_OFF, 0x00020000);
+    if constexpr (PRE) {
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const int pr = r0v + RPP * i;
-      const int py = pr / PW, px = pr - py * PW;
-      const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
-      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-      const unsigned off = !ok ? DG_OOB_OFF : (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16;
-      rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      for (int i = 0; i < NPL; ++i) {
+        const int w = (int)__builtin_amdgcn_ubfe(i < 8 ? p_wlo : p_whb, i < 8 ? 4 * i : 4 * (i - 8), 4);
+        const unsigned bad = (unsigned)__builtin_amdgcn_sbfe((int)p_whb, 16 + i, 1);          // all ones when the chunk is outside
+        const unsigned off = ((unsigned)__mul24(w, p_Bd) + p_off0 + (unsigned)(i * p_A)) | bad;  // >= DG_OOB_OFF: the load returns 0
+        rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
-    for (int i = 0; i < NPS; ++i) {               // scale words of patch rows tid (and tid + 256)
-      const int pr = tid + NT * i;
-      const int py = pr / PW, px = pr - py * PW;
-      const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
-      const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-      rps[i] = __builtin_amdgcn_raw_buffer_load_b32(rxs, ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * ldxs) : DG_OOB_OFF, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < NPS; ++i) {
+        rps[i] = __builtin_amdgcn_raw_buffer_load_b32(rxs, p_soff[i], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      int r0v = r0;
+      asm volatile("" : "+v"(r0v));
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int pr = r0v + RPP * i;
+        const int py = pr / PW, px = pr - py * PW;
+        const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
+        const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+        const unsigned off = !ok ? DG_OOB_OFF : (unsigned)(((sy - sy_base) * a.Ws + sx) * a.ldx * ES) + cc * 16;
+        rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < NPS; ++i) {               // scale words of patch rows tid (and tid + 256)
+        const int pr = tid + NT * i;
+        const int py = pr / PW, px = pr - py * PW;
+        const int sy = S2 ? 2 * (ty0 - 1 + py) + ppy : ty0 - 1 + py, sx = S2 ? 2 * (tx0 - 1 + px) + ppx : tx0 - 1 + px;
+        const bool ok = pr < PROWS && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+        rps[i] = __builtin_amdgcn_raw_buffer_load_b32(rxs, ok ? (unsigned)(((sy - sy_base) * a.Ws + sx) * ldxs) : DG_OOB_OFF, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   char* const st_base = s_patch + r0 * PITCH + cc * 16;
@@ -284,6 +333,7 @@ static int gg_launch_halo4w_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st
 }
 
 int gg_launch_halo_f8(GGArgs& a, const F8Args& f, int N, bool s2, int nw, hipStream_t st) {
+  if (nw == 8 && 2ll * a.Ws * a.ldx >= (1ll << 23)) nw = 4;            // the eight-wave instance multiplies the row step in 24 bits
   if (a.seg) return gg_launch_halo4w_f8<false, 4, true>(a, f, N, st);
   if (!s2) return gg_launch_halo4w_f8<false>(a, f, N, st);
   return nw == 8 ? gg_launch_halo4w_f8<true, 8>(a, f, N, st) : gg_launch_halo4w_f8<true>(a, f, N, st);

@@ -237,7 +237,10 @@ def test_bf16_learning_curve_tracks_fp32_on_a_learnable_task():
     a = [v for _, v in res["runs"]["f32"]["content_loss_generator_steps"]]
     b = [v for _, v in res["runs"]["bf16"]["content_loss_generator_steps"]]
     assert len(a) == 6 and all(abs(x - y) <= 5e-3 * x for x, y in zip(a, b)), (a, b)
-    assert all(abs(x - y) <= 2e-2 * max(abs(x), 1.0) for x, y in zip(res["runs"]["f32"]["critic_loss"][:10], res["runs"]["bf16"]["critic_loss"][:10]))
+    # the critic loss swings over +-600 in these steps and crosses zero (..., 640, -282, -110, -14, 28, ...): 2 % of the value plus
+    # 1.0 absolute -- two runs of ONE precision differ by up to 0.05 near the crossing (order of the fp32 atomics), bf16 from fp32 by 0.2
+    cl32, cl16 = res["runs"]["f32"]["critic_loss"][:10], res["runs"]["bf16"]["critic_loss"][:10]
+    assert all(abs(x - y) <= 2e-2 * abs(x) + 1.0 for x, y in zip(cl32, cl16)), (cl32, cl16)
 
 
 def test_hip_graph_replay_equals_eager():

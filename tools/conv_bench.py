@@ -30,10 +30,13 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
     ap.add_argument("--layers", default="", help="comma-separated substrings of layer names to run")
+    ap.add_argument("--f8", action="store_true", help="MXFP8 kernels (operands quantised beforehand; implies --net C, bf16, wide layers only)")
     ap.add_argument("--net", default="", help='layer tag ("C" makes the wide layers eligible for the fp8 kernels with --dtype fp8)')
     ap.add_argument("--nscale", type=int, default=1, help="multiply every layer's batch (the table uses small batches)")
     args = ap.parse_args()
-    o = HipOps(args.dtype)
+    o = HipOps(args.dtype, f8_critic=args.f8)
+    if args.f8:
+        args.net = "C"
     g = torch.Generator().manual_seed(0)
     for name, N, H, ci, co, st, ps in LAYERS:
         N *= args.nscale
@@ -48,8 +51,14 @@ def main():
         dw = o.zeros(co * 9 * ci, dtype=torch.float32)
         fl = o.conv_flops(cv)
         res = []
+        q = {}
+        if args.f8 and o.f8_eligible(cv, "fwd"):
+            q["xq"], q["wq"] = o.quant_mxfp8(x), o.quant_mxfp8(w.view(co * 9, ci))
+        if args.f8 and o.f8_eligible(cv, "dgrad") and not ps:
+            q["dyq"], q["wdq"] = o.quant_mxfp8(dy), o.quant_mxfp8(w.view(ci * 9, co))
         for op in args.ops.split(","):
-            fn = {"fwd": lambda: o.conv_fwd(cv, x, w, y, act=0.2), "dgrad": lambda: o.conv_dgrad(cv, dy, w, dx),
+            fn = {"fwd": lambda: o.conv_fwd(cv, x, w, y, xq=q.get("xq"), wq=q.get("wq"), act=0.2),
+                  "dgrad": lambda: o.conv_dgrad(cv, dy, w, dx, xq=q.get("dyq"), wq=q.get("wdq")),
                   "wgrad": lambda: o.conv_wgrad(cv, x, dy, dw)}[op]
             if op == "dgrad" and ci % 16:
                 continue
