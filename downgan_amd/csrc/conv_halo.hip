@@ -13,6 +13,13 @@ __device__ unsigned long long g_stamps[2 * 8 * 8];
 extern "C" int dg_debug_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
 }
+// ... and the life of every workgroup of the last launch (up to DG_WGLOG_MAX): {HW_ID | XCC_ID << 32, start, end} of wave 0, to
+// reconstruct per-CU residency (tools/stamp_probe.py --residency)
+#define DG_WGLOG_MAX 16384
+__device__ unsigned long long g_wglog[DG_WGLOG_MAX * 3];
+extern "C" int dg_debug_wglog(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wglog), sizeof(unsigned long long) * 3 * (n < DG_WGLOG_MAX ? n : DG_WGLOG_MAX)) == hipSuccess ? 0 : 1;
+}
 #define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP(v) do { } while (0)
@@ -325,8 +332,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
   else halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
 #ifdef DG_STAMP
   STAMP(tX);
-  if (blockIdx.x < 2 && lane == 0) {
-    unsigned long long* o = g_stamps + (blockIdx.x * 8 + wave) * 8;
+  if (blockIdx.x < DG_WGLOG_MAX && tid == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = g_wglog + (unsigned long long)blockIdx.x * 3;
+    o[0] = (unsigned long long)hw | ((unsigned long long)xcc << 32); o[1] = tK0; o[2] = tX;
+  }
+  // two workgroups from the MIDDLE of the launch (steady state: the first round starts in lock-step and runs ~25 % faster per step)
+  const unsigned sb = blockIdx.x - a.nwg / 2;
+  if (sb < 2u && lane == 0) {
+    unsigned long long* o = g_stamps + (sb * 8 + wave) * 8;
     o[0] = sAB; o[1] = sBC; o[2] = sCD; o[3] = sDE; o[4] = (unsigned long long)nsteps; o[5] = tL1 - tL0; o[6] = tX - tL1; o[7] = tL0 - tK0;
   }
 #endif

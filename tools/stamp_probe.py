@@ -11,9 +11,9 @@ from downgan_amd.ops import Conv, HipOps
 
 o = HipOps("bf16")
 g = torch.Generator().manual_seed(0)
-CASES = [("G.b5 640->128@128", 16, 128, 640, 128, 1, "fwd"), ("C.l6 512->1024@128", 16, 128, 512, 1024, 1, "fwd"),
-         ("G.b1 128->128@128", 16, 128, 128, 128, 1, "fwd"), ("C.l1 128->128 s2 @1024 dgrad, activation mask (last class launch: 4 taps)", 2, 1024, 128, 128, 2, "dgrad"),
-         ("C.l1 dgrad, bit mask", 2, 1024, 128, 128, 2, "dgrad_bits"), ("C.l1 dgrad, no mask", 2, 1024, 128, 128, 2, "dgrad_nomask")]
+CASES = [("G.b5 640->128@128", 64, 128, 640, 128, 1, "fwd"), ("C.l6 512->1024@128", 32, 128, 512, 1024, 1, "fwd"),
+         ("G.b1 128->128@128", 64, 128, 128, 128, 1, "fwd"), ("C.l1 128->128 s2 @1024 dgrad, activation mask (merged classes)", 8, 1024, 128, 128, 2, "dgrad"),
+         ("C.l1 dgrad, bit mask", 8, 1024, 128, 128, 2, "dgrad_bits"), ("C.l1 dgrad, no mask", 8, 1024, 128, 128, 2, "dgrad_nomask")]
 for name, N, H, ci, co, st, op in CASES:
     cv = Conv(N, H, H, ci, co, st)
     x = torch.randn(N, H, H, ci, generator=g).to(o.tdtype).cuda()
