@@ -134,6 +134,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C downgan_amd/csrc`. downgan_amd has no CPU or eager fallback.")
+        # torch first: the library's kernels must register with the HIP runtime torch brings along (its own libamdhip64), the one
+        # whose streams and device pointers the C ABI is handed.  Loaded before torch, the library binds /opt/rocm's copy and every
+        # launch on a torch stream fails (seen as DG_ERR_LAUNCH from the first kernel when build() and smoke() share a process).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         l.dg_version.restype = C.c_char_p
         l.dg_version.argtypes = []
