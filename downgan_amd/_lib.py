@@ -126,8 +126,37 @@ EXPORTS = ["dg_version"] + list(_PROTOS)
 _lib = None
 
 
+def _object_of(handle, symbol="hipGetDeviceCount"):
+    """Path of the mapped shared object that ``symbol`` resolves to when looked up through ``handle`` (dlsym searches the object
+    and its dependencies, so for a library linked against libamdhip64 this names the HIP runtime its kernels register with)."""
+    try:
+        addr = C.cast(getattr(handle, symbol), C.c_void_p).value
+    except AttributeError:
+        return None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            parts = line.split(None, 5)
+            if len(parts) < 6:
+                continue
+            lo, hi = (int(x, 16) for x in parts[0].split("-"))
+            if lo <= addr < hi:
+                return os.path.realpath(parts[5].strip())
+    return None
+
+
+def hip_runtime_binding(l=None):
+    """(runtime libdowngan_hip.so is bound to, runtime torch's HIP libraries are bound to); either may be None when it cannot be
+    determined (a torch build without HIP libraries)."""
+    import torch
+    mine = _object_of(l if l is not None else C.CDLL(LIB_PATH))
+    c10 = os.path.join(os.path.dirname(torch.__file__), "lib", "libc10_hip.so")
+    theirs = _object_of(C.CDLL(c10)) if os.path.exists(c10) else None
+    return mine, theirs
+
+
 def lib():
-    """Load (once) and return the shared library; raise loudly when it has not been built."""
+    """Load (once) and return the shared library; raise loudly when it has not been built, or when it is bound to another HIP
+    runtime than torch's."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -139,6 +168,15 @@ def lib():
         # launch on a torch stream fails (seen as DG_ERR_LAUNCH from the first kernel when build() and smoke() share a process).
         import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
+        # ... and verified: a host process that mapped libdowngan_hip.so (or another libamdhip64 with the same soname) BEFORE torch
+        # has bound the library to that runtime for good -- say so here instead of failing every launch with DG_ERR_LAUNCH later
+        mine, theirs = hip_runtime_binding(l)
+        if mine is not None and theirs is not None and mine != theirs:
+            raise RuntimeError(
+                f"libdowngan_hip.so is bound to the HIP runtime {mine}, torch to {theirs}: two HIP runtimes in one process. The "
+                "library's kernels are registered with the first, while the streams and device pointers it is handed belong to the "
+                "second, so every launch would fail (DG_ERR_LAUNCH). Import torch (or downgan_amd, which does) before anything that "
+                "loads libdowngan_hip.so or /opt/rocm's libamdhip64 into this process.")
         l.dg_version.restype = C.c_char_p
         l.dg_version.argtypes = []
         for name, args in _PROTOS.items():

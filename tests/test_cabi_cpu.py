@@ -153,3 +153,24 @@ def test_oracle_is_only_used_as_the_checker():
         return out
     assert importing_functions(os.path.join(ROOT, "bench.py")) <= {"cpu_baseline"}
     assert importing_functions(os.path.join(ROOT, "__graft_entry__.py")) <= {"smoke"}
+
+
+def test_hip_runtime_binding_is_checked_in_both_load_orders():
+    """The library must be bound to the HIP runtime torch uses (the C ABI is handed torch's streams and device pointers).  torch
+    first (what ``_lib.lib()`` does itself): one runtime, loads.  The shared object mapped BEFORE torch (a host process that
+    dlopen-ed it, or /opt/rocm's libamdhip64, early): it is bound to /opt/rocm's runtime for good -- ``lib()`` must say so instead
+    of leaving every later launch to fail with DG_ERR_LAUNCH (round 3: build() and smoke() in one process)."""
+    import subprocess
+    import sys
+    ok = subprocess.run([sys.executable, "-c",
+                         "from downgan_amd import _lib; l = _lib.lib(); m, t = _lib.hip_runtime_binding(l); assert m == t, (m, t); print('bound', m)"],
+                        cwd=ROOT, capture_output=True, text=True)
+    assert ok.returncode == 0 and "bound" in ok.stdout, ok.stderr[-600:]
+    if not os.path.exists("/opt/rocm/lib/libamdhip64.so"):
+        pytest.skip("no second HIP runtime on this machine to provoke the mismatch with")
+    for first in (f"ctypes.CDLL({_lib.LIB_PATH!r})", "ctypes.CDLL('/opt/rocm/lib/libamdhip64.so', mode=ctypes.RTLD_GLOBAL)"):
+        bad = subprocess.run([sys.executable, "-c", f"import ctypes; {first}; from downgan_amd import _lib; _lib.lib()"],
+                             cwd=ROOT, capture_output=True, text=True)
+        if bad.returncode == 0:       # this torch build resolved to the same runtime object: nothing to complain about
+            continue
+        assert "RuntimeError" in bad.stderr and "two HIP runtimes in one process" in bad.stderr, (first, bad.stderr[-600:])
