@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — train-step samples/sec (G+D+GP) of the native WGAN-GP step on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`.  For N>1 either the driver starts the ranks
+Contract: `python bench.py --gpus N --steps K --warmup W`.  One command per BASELINE config: `--workload cfg1|cfg2|cfg3|cfg4|cfg5`
+(= configs[0..4]; cfg3 is quoted on --gpus 8, cfg4 on --gpus 4, cfg5 on --gpus 8 and defaults to --dtype fp8).  For N>1 either the driver starts the ranks
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, WORLD_SIZE set) or, typed bare, this
 script starts them itself (`self_launch`: N fresh child processes before any GPU call); one rank per GPU over RCCL.  A "step" is one minibatch through the critic iteration plus the
 generator iteration when step % 5 == 0 (reference DoWnGAN/GAN/wasserstein.py:131-147; the metrics
@@ -30,10 +31,18 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0, "fp8c": 5000.0}
 
 WORKLOADS = {
     # name: (batch per GPU, coarse side, filters, channels, RRDBs)
-    "cfg2": (32, 128, 128, 2, 16),          # BASELINE.json configs[1] (and [2] at 8 GPUs: global batch 256)
-    "cfg4": (16, 128, 128, 6, 16),          # 6-covariate input, global batch 64 on 4 GPUs
-    "cfg1": (4, 16, 16, 2, 16),             # the reference's CPU-runnable plumbing case
+    "cfg2": (32, 128, 128, 2, 16),          # BASELINE.json configs[1]: batch 32, 1x MI355X, bf16 (the headline)
+    "cfg3": (32, 128, 128, 2, 16),          # BASELINE.json configs[2]: batch 256 = 32/GPU x 8 GPUs, RCCL gradient all-reduce
+    "cfg4": (16, 128, 128, 6, 16),          # BASELINE.json configs[3]: 6-covariate input, batch 64 = 16/GPU x 4 GPUs
+    "cfg5": (16, 128, 128, 2, 16),          # BASELINE.json configs[4]: fp8 conv path, batch 128 = 16/GPU x 8 GPUs
+    "cfg1": (4, 16, 16, 2, 16),             # BASELINE.json configs[0]: the reference's CPU-runnable plumbing case
     "mid": (4, 64, 64, 2, 4),               # small GPU sanity workload
+}
+# one unambiguous command per BASELINE config: the rank count and precision each named workload is quoted on (--gpus / --dtype
+# still override; `config.workload` says what actually ran)
+WORKLOAD_INFO = {
+    "cfg1": ("BASELINE configs[0]", 1, "bf16"), "cfg2": ("BASELINE configs[1]", 1, "bf16"), "cfg3": ("BASELINE configs[2]", 8, "bf16"),
+    "cfg4": ("BASELINE configs[3]", 4, "bf16"), "cfg5": ("BASELINE configs[4]", 8, "fp8"), "mid": ("sanity workload, not a BASELINE config", 1, "bf16"),
 }
 
 
@@ -159,7 +168,7 @@ def self_launch(n):
     Runs BEFORE anything initialises the GPU in this process; the children are new processes, nothing is re-exec'ed."""
     import socket
     import subprocess
-    with socket.socket() as sk:
+    with socket.socket() as sk:          # (downgan_amd.dist.free_port, inlined: this parent process must not import torch)
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -286,8 +295,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8", "fp8c"],
-                    help="fp8 = BASELINE configs[4]: forward / data-gradient convs of the critic's 128..1024-channel layers AND the forward "
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8", "fp8c"],
+                    help="default: the workload's own (bf16; fp8 for cfg5).  fp8 = BASELINE configs[4]: forward / data-gradient convs of the critic's 128..1024-channel layers AND the forward "
                          "of the generator's dense-block trunk on the MXFP8 MFMA (fp32 accumulate), everything else as in bf16; "
                          "fp8c = the critic's layers only")
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
@@ -306,6 +315,8 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gradient exchange goes over gloo")
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = WORKLOAD_INFO[args.workload][2]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: this parent process never imports torch and never touches the GPU; it starts N
@@ -336,6 +347,16 @@ def main():
     if dist:
         ranks_seen = [None] * world
         torch.distributed.all_gather_object(ranks_seen, me)
+        # a multi-GPU number needs `world` DISTINCT devices: ranks piled onto one GPU (a launcher that lost LOCAL_RANK, a
+        # visibility mask per rank) would still print a line.  Only the explicit one-GPU rehearsal may share a device.
+        devs = {r["device"] for r in ranks_seen}
+        if not args.rehearse_on_one_gpu and (len(devs) != world or any(r["visible_devices"] < world for r in ranks_seen)):
+            if rank == 0:
+                print(json.dumps({"error": f"--gpus {world}: the ranks compute on {len(devs)} distinct device(s) {sorted(devs)}; "
+                                           "not a multi-GPU run (use --rehearse-on-one-gpu for a one-GPU rehearsal)", "ranks_seen": ranks_seen}), flush=True)
+            dist.barrier()
+            sys.exit(3)
+        dist.track_overlap()
 
     if args.graphs:
         eng.enable_graphs(xc, xf)
@@ -343,8 +364,11 @@ def main():
     for s in range(args.warmup):
         eng.train_step(xc, xf, alphas[s])
     gen_steps_timed = -(-args.steps // eng.hp.critic_iterations)
+    if dist:
+        dist.track_overlap()                  # count from the timed region on
     elapsed, prof = timed_steps(eng, ops, xc, xf, alphas, args.warmup, args.steps, dist, args.rehearse_on_one_gpu,
                                 not args.no_kernel_timing, args.per_layer)
+    overlap = dict(dist.overlap) if dist else None
     scal = eng.read_scalars(True)
     peak = MFMA_PEAK_TFLOPS["bf16" if is_f8 else args.dtype]      # gg_halo4w_kernel is a bf16 / fp32 kernel in every mode
     roofline, critic_stack, kernels = summarise_kernels(prof, elapsed, args.steps, peak, args, args.per_layer)
@@ -394,7 +418,10 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "ZEROS (clock diagnostic, not a result)" if args.zero_data else "synthetic",
             "rehearsal": bool(args.rehearse_on_one_gpu),
-            "config": {"workload": f"{args.workload}: batch {B}/GPU (global {B * world}), {cin}ch {S}x{S}->{8 * S}x{8 * S}, "
+            "config": {"workload": f"{args.workload} ({WORKLOAD_INFO[args.workload][0]}"
+                                   + ("" if (world, args.dtype) == WORKLOAD_INFO[args.workload][1:] or args.workload == "mid" else
+                                      f", quoted on {WORKLOAD_INFO[args.workload][1]} GPU(s) in {WORKLOAD_INFO[args.workload][2]}: THIS run is {world} GPU(s) in {args.dtype}")
+                                   + f"): batch {B}/GPU (global {B * world}), {cin}ch {S}x{S}->{8 * S}x{8 * S}, "
                                    f"filters {F_}, {nrb} RRDBs, WGAN-GP critic step every step + generator step every 5th",
                        "parallelism": f"dp{world}", "per_gpu_batch": B, "global_batch": B * world,
                        "exchange": (None if world == 1 else "gloo over host memory, all ranks on cuda:0 (REHEARSAL: not a multi-GPU measurement)"
@@ -407,6 +434,9 @@ def main():
                        "generator_steps_in_timed_region": gen_steps_timed,
                        "critic_passes_stacked": stacked},
             "ranks_seen": ranks_seen,
+            "exchange_overlap": (None if overlap is None else dict(overlap, what=(
+                "deferred gradient exchanges whose all-reduce had ALREADY completed (non-blocking query of the last bucket) when the "
+                "consumer reached its wait: already_complete == finishes means the exchange was fully hidden behind the next forward pass"))),
             "hbm_peak_gib": round(hbm_peak / 2 ** 30, 1),
             "step_mfma_frac": round(w_step * value / world / 1e12 / peak, 4),
             "losses": {k: scal[k] for k in ("critic_loss", "gp_ret", "g_loss") if k in scal},

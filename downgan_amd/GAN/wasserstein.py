@@ -51,9 +51,10 @@ class WassersteinGAN:
         B, cin, S, _ = coarse.shape
         if self._engine is None or (self._engine.B, self._engine.S) != (B, S):
             assert self.G.dtype == self.C.dtype
-            carry = None
+            carry = old_shape = None
             if self._engine is not None and self._engine.S == S:
                 old = self._engine
+                old_shape = (old.B, tuple(self._stage[1].shape[1:3]))
                 carry = (old.G.P.export_state(), old.C.P.export_state())      # flat fp32 buffers only (8.8 GB at cfg2)
                 self.G._bound = self.C._bound = None                          # (no host round trip: the state moves on the device)
                 self._engine = self._stage = old = None
@@ -61,21 +62,38 @@ class WassersteinGAN:
                 gc.collect()
                 if torch.cuda.is_available():
                     torch.cuda.empty_cache()
-            ops = backend.make_ops(self.G.dtype, self.G.device)
-            e = TrainEngine(ops, S, self.G.filters, cin, B, hp.as_engine_hp(B), self.G.n_predictands,
-                            self.G.num_res_blocks, self.G.num_upsample, dist=self.dist, check_finite=self.check_finite)
-            if carry is not None:
-                e.G.P.import_state(carry[0]); e.C.P.import_state(carry[1])
-                self.G.bind(e.G, load=False); self.C.bind(e.C, load=False)
-                del carry
-            else:
-                self.G.bind(e.G)
-                self.C.bind(e.C)
-            self._adopt_optimizers(e)
-            e.num_steps = self.num_steps
-            self._engine = e
-            self._stage = (ops.zeros(B, S, S, e.G.cin_p), ops.zeros(B, fine.shape[2], fine.shape[3], e.G.np_p))
+            try:
+                e = self._build(B, cin, S, carry)
+            except Exception:
+                # The live parameters and Adam state exist only in ``carry`` now (the old engine was released to make room).  Put
+                # them back into an engine of the size that was running, so that state_dict() / checkpoints / the next batch see
+                # the trained weights and not the networks' stale host copies; then let the caller see the failure.
+                if carry is not None and old_shape is not None:
+                    import gc
+                    gc.collect()
+                    if torch.cuda.is_available():
+                        torch.cuda.empty_cache()
+                    self._install(self._build(old_shape[0], cin, S, carry), old_shape[1])
+                raise
+            self._install(e, (fine.shape[2], fine.shape[3]))
         return self._engine
+
+    def _build(self, B, cin, S, carry):
+        ops = backend.make_ops(self.G.dtype, self.G.device)
+        e = TrainEngine(ops, S, self.G.filters, cin, B, hp.as_engine_hp(B), self.G.n_predictands,
+                        self.G.num_res_blocks, self.G.num_upsample, dist=self.dist, check_finite=self.check_finite)
+        if carry is not None:
+            e.G.P.import_state(carry[0]); e.C.P.import_state(carry[1])
+        return e, carry is not None
+
+    def _install(self, built, fine_hw):
+        e, carried = built
+        self.G.bind(e.G, load=not carried)
+        self.C.bind(e.C, load=not carried)
+        self._adopt_optimizers(e)
+        e.num_steps = self.num_steps
+        self._engine = e
+        self._stage = (e.ops.zeros(e.B, e.S, e.S, e.G.cin_p), e.ops.zeros(e.B, fine_hw[0], fine_hw[1], e.G.np_p))
 
     def _adopt_optimizers(self, e):
         e.adam_hp[id(e.G.P)] = _adam_config(self.G_optimizer, e.hp)
@@ -131,6 +149,18 @@ class WassersteinGAN:
     def gen_batch_and_log_metrics(self, coarse, fine):
         """Native version of mlflow_tools/mlflow_epoch.py:53-63 (the per-step metrics pass, wasserstein.py:140):
         returns {"MAE", "MSE", "Wass", "MSSSIM"} (MSSSIM None for tiles too small for 5 scales)."""
+        e, n = self._engine, coarse.shape[0]
+        if (e is not None and n < e.B and coarse.shape[2] == e.S and not hasattr(coarse, "nhwc")
+                and (e.dist is None or e.world == 1)):
+            # a smaller batch (a test loader's own batch size, a ragged last batch) on the TRAINING engine's buffers, padded:
+            # re-binding would tear down and re-allocate every training buffer (142 GiB at configs[1]) for one G forward and two
+            # critic forwards, and once more when the next training batch arrives.  Larger batches still re-bind (the MS-SSIM
+            # normalisation runs over the whole batch, losses.py:15-29, so they cannot be split).
+            o = e.ops
+            xc, xf = self._stage
+            o.nchw_to_nhwc(coarse.to(device=o.device, dtype=torch.float32).contiguous(), xc[:n])
+            o.nchw_to_nhwc(fine.to(device=o.device, dtype=torch.float32).contiguous(), xf[:n])
+            return e.metrics_pass(xc, xf, n_valid=n)
         e = self._eng(coarse, fine)
         xc, xf = self._to_native(e, coarse, fine)
         return e.metrics_pass(xc, xf)

@@ -77,6 +77,7 @@ _PROTOS = {
     "dg_gather_gemm": [C.POINTER(GGDesc), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_plan": [C.POINTER(ConvGeom), _i, C.POINTER(GGDesc)],
     "dg_last_conv_kernels": [],
+    "dg_conv3x3_dgrad_launches": [C.POINTER(ConvGeom)],
     "dg_colsum": [_i, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp],
     "dg_repack_conv_weights": [_i, _i, _vp, _vp, _i, _i, _vp],
     "dg_repack_dense_dgrad": [_i, _vp, _i, _i, _vp, _vp],

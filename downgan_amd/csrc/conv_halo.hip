@@ -362,8 +362,9 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
 }
 
 int gg_launch_halo(GGArgs& a, int dtype, int N, bool s2, bool ps, int nw, hipStream_t st) {
-  // the kernel forms patch offsets with 24-bit multiplies of the row step (bytes between patch rows)
-  if ((long long)(ps ? 4 : s2 ? 2 : 1) * a.Ws * a.ldx * (dtype == DG_F32 ? 4 : 2) >= (1ll << 23)) return gg_launch_rows(a, dtype, st);
+  // the kernel forms patch offsets with 24-bit multiplies of the row step (bytes between patch rows); conv_plan.hip routes
+  // oversized rows to the row-tiled kernel BEFORE it regroups taps / merges classes, so this is a guard, not a fallback
+  if (!gg_halo_row_step_ok(a.Ws, a.ldx, dtype, ps ? 4 : s2 ? 2 : 1)) return DG_ERR_BAD_SHAPE;
   if (a.seg) return dtype == DG_BF16 ? gg_launch_halo4w<bf16_t, false, false, 4, true>(a, N, st) : gg_launch_halo4w<float, false, false, 4, true>(a, N, st);
   if (dtype == DG_F32) {
     if (ps) return gg_launch_halo4w<float, false, true>(a, N, st);

@@ -31,19 +31,31 @@ static int gg_validate(const dg_gg_desc* d, bool f8 = false, bool compact_src = 
   return DG_OK;
 }
 
+// The halo kernel forms its patch offsets with 24-bit multiplies of the row step (bytes between two patch rows: 1 / 2 / 4 source
+// rows for the plain / stride-2 / pixel-shuffled gathers).  Decided HERE, on the descriptor as planned: the row-tiled fallback knows
+// neither the plane-regrouped tap codes of the stride-2 forward nor the merged parity classes of a stride-2 data gradient.
+bool gg_halo_row_step_ok(long long Ws, long long ldx, int dtype, int mult) {
+  return mult * Ws * ldx * (dtype == DG_F32 ? 4 : 2) < (1ll << 23);
+}
+
 // Kernel choice for one descriptor (bf16 / fp32).
 static int gg_launch(GGArgs& a, int dtype, int N, hipStream_t st) {
+  if (a.seg) {     // merged classes (seg_dgrad_desc has checked shape and row step): the halo kernel is the only one that knows them
+    if (!gg_halo_row_step_ok(a.Ws, a.ldx, dtype, 1)) return DG_ERR_BAD_SHAPE;
+    return gg_launch_halo(a, dtype, N, false, false, 4, st);
+  }
   // halo kernel: the patch is sized for tap shifts in [-1, 1] around a unit-stride grid (stride-1 forward, all data gradients;
   // also single-tap launches: the 1-tap parity class of a stride-2 data gradient)
-  if (a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 && a.Hs == a.Hg && a.Ws == a.Wg)
+  if (a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && a.cch % 8 == 0 && a.Nout > 64 && a.Hg >= 8 && a.Wg >= 8 && a.Hs == a.Hg && a.Ws == a.Wg &&
+      gg_halo_row_step_ok(a.Ws, a.ldx, dtype, 1))
     return gg_launch_halo(a, dtype, N, false, false, 4, st);
   // pixel-shuffled sources (data gradients of the up-sampling convs) whose channel quarters hold whole 64-channel blocks
   if (a.sy_mul == 1 && a.sx_mul == 1 && a.src_ps && a.cps_src_chunks % 8 == 0 && a.cch % 8 == 0 && a.Nout > 64 &&
-      a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 && a.Hs == a.Hg && a.Ws == a.Wg)
+      a.Hg >= 8 && a.Wg >= 8 && a.ntaps >= 2 && a.Hs == a.Hg && a.Ws == a.Wg && gg_halo_row_step_ok(a.Ws, a.ldx, dtype, 4))
     return gg_launch_halo(a, dtype, N, false, true, 4, st);
   // stride-2 forward through the four parity planes of the input
   if (a.sy_mul == 2 && a.sx_mul == 2 && !a.src_ps && a.cch % 16 == 0 && a.Nout > 64 && a.Hg >= 8 &&
-      a.Wg >= 8 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1)
+      a.Wg >= 8 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1 && gg_halo_row_step_ok(a.Ws, a.ldx, dtype, 2))
   {
     GGArgs b = a;
     if (gg_regroup_taps_by_plane(b)) {
@@ -219,6 +231,7 @@ static bool seg_dgrad_desc(const dg_gg_desc* d, int n, dg_gg_desc* out) {
   const int epc = d[0].dtype == DG_F32 ? 4 : 8;
   if (off || n != 4 || d[0].src_ps || d[0].dst_ps || (d[0].Cred / epc) % 8 || d[0].Nout <= 64 || d[0].Hg < 8 || d[0].Wg < 8) return false;
   if (d[0].ntaps != 1 || d[1].ntaps != 2 || d[2].ntaps != 2 || d[3].ntaps != 4) return false;
+  if (!gg_halo_row_step_ok(d[0].Ws, d[0].lds, d[0].dtype, 1)) return false;     // oversized rows: four launches on the row-tiled kernel
   *out = d[3];
   out->ntaps = 0;
   for (int c = 0; c < 4; ++c) {
@@ -277,3 +290,12 @@ extern "C" int dg_conv3x3_dgrad_f8(const dg_conv_geom* g, const dg_epilogue* ep,
 }
 
 extern "C" int dg_last_conv_kernels(void) { return g_last_kinds; }
+
+// Host-side probe of the planner (no GPU): how a stride-2 data gradient of geometry `g` would be launched --
+// 1 = one merged launch of the halo kernel (conv_halo.hip, SEG), 4 = one launch per parity class, < 0 = dg_status.
+extern "C" int dg_conv3x3_dgrad_launches(const dg_conv_geom* g) {
+  dg_gg_desc d[4], ds;
+  const int n = dg_conv3x3_plan(g, 1, d);
+  if (n < 0) return n;
+  return seg_dgrad_desc(d, n, &ds) ? 1 : n;
+}

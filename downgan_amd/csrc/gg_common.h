@@ -530,6 +530,7 @@ struct F8Args { const unsigned char* xs; const unsigned char* ws; int ldxs; };  
 // ---- launchers of the kernel families (one translation unit each); dtype = DG_F32 / DG_BF16, N = images
 int gg_launch_rows(GGArgs& a, int dtype, hipStream_t st);
 bool gg_regroup_taps_by_plane(GGArgs& a);
+bool gg_halo_row_step_ok(long long Ws, long long ldx, int dtype, int mult);
 int gg_launch_halo(GGArgs& a, int dtype, int N, bool s2, bool ps, int nw, hipStream_t st);
 int gg_launch_halo_f8(GGArgs& a, const F8Args& f, int N, bool s2, int nw, hipStream_t st);
 int gg_launch_halo16(GGArgs& a, int dtype, int N, hipStream_t st);

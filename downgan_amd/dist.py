@@ -16,6 +16,14 @@ import torch  # noqa: E402
 import torch.distributed as td  # noqa: E402
 
 
+def free_port() -> int:
+    """An unused TCP port on 127.0.0.1, for the launcher to export as MASTER_PORT to all of its ranks."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
 class Dist:
     def __init__(self, backend=None, bucket_elems=64 * 1024 * 1024):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -27,7 +35,11 @@ class Dist:
         self.backend = backend
         if self.world_size > 1 and not td.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            if "MASTER_PORT" not in os.environ:
+                # every launcher (bench.py, torch.distributed.run, tests) exports the port; ranks started some other way cannot agree
+                # on a free one by themselves, and a fixed fallback collides with whatever else runs on the node
+                raise RuntimeError("Dist: WORLD_SIZE > 1 but MASTER_PORT is not set; export the rendezvous port every rank shares "
+                                   "(downgan_amd.dist.free_port() picks an unused one in the launcher)")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
             td.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
@@ -43,11 +55,35 @@ class Dist:
             works.append(td.all_reduce(flat[off:min(n, off + self.bucket_elems)], op=td.ReduceOp.SUM, async_op=True))
         return works
 
-    @staticmethod
-    def allreduce_finish(works):
+    overlap = None      # {"finishes": n, "already_complete": k}: set by track_overlap()
+
+    def track_overlap(self):
+        """Count, from now on, how many deferred exchanges had ALREADY completed when their ``allreduce_finish`` was reached (a
+        non-blocking query of the last bucket's work handle): the first multi-GPU run then shows whether the overlap with the
+        following forward pass is real (bench.py reports the counts)."""
+        self.overlap = {"finishes": 0, "already_complete": 0}
+
+    def allreduce_finish(self, works):
         """Make the current stream (nccl) / the host (gloo) wait for the enqueued all-reduces."""
+        if self.overlap is not None and works:
+            self.overlap["finishes"] += 1
+            try:
+                self.overlap["already_complete"] += int(bool(works[-1].is_completed()))
+            except Exception:      # a backend without a non-blocking query
+                pass
         for w in works:
             w.wait()
+
+    def any_rank(self, flag: bool) -> bool:
+        """Logical OR of a per-rank condition over all ranks (one small MAX all-reduce): so that every rank takes the same
+        decision -- e.g. raises together instead of one rank raising and the others hanging in the next collective."""
+        if self.world_size == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if self.backend == "nccl":
+            t = t.cuda()
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return bool(int(t.item()))
 
     def allreduce_sum_(self, flat: torch.Tensor):
         self.allreduce_finish(self.allreduce_sum_begin(flat))

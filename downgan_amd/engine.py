@@ -905,6 +905,13 @@ class TrainEngine:
         bufs = [("loss scalars", self.scal), (f"{where} gradients (flat buffer)", P.g), ("generated batch G(coarse)", self.G.fake)] + list(extra)
         counts = self.ops.count_nonfinite(bufs)
         bad = [(n, c) for n, c in counts.items() if c]
+        # data parallel: the ranks decide TOGETHER (one small MAX all-reduce) -- a NaN seen by one rank only (its own samples) must
+        # not leave the others blocked in the gradient all-reduce behind a rank that has already raised
+        if self.dist is not None and self.world > 1:
+            any_bad = self.dist.any_rank(bool(bad))
+            if any_bad and not bad:
+                raise FloatingPointError(f"check_finite: step {self.num_steps}, {where} iteration: non-finite values on another rank "
+                                         f"(this rank, {getattr(self.dist, 'rank', '?')}, is clean)")
         if bad:
             detail = ""
             if bad[0][0].endswith("(flat buffer)"):      # name the parameters (host side, only on failure)
@@ -998,34 +1005,41 @@ class TrainEngine:
         if apply_update:
             self._allreduce_and_step(G.P, defer=True)             # :83 (overlaps with the next critic iteration's real pass)
 
-    def metrics_pass(self, coarse, fine):
+    def metrics_pass(self, coarse, fine, n_valid=None):
         """Per-batch evaluation metrics of the reference's training loop (mlflow_tools/mlflow_epoch.py:53-63 called at
         wasserstein.py:140): MAE = L1(real, G(x)) (losses.py:40-55), MSE (losses.py:58-70), Wass = mean C(real) -
         mean C(G(x)) (losses.py:8-9), MSSSIM = MS-SSIM of the batch-min-max-normalised fields (losses.py:12-38; msssim.py).
-        MSSSIM is None when the tile is too small for 5 scales (pytorch_msssim asserts side > 96)."""
+        MSSSIM is None when the tile is too small for 5 scales (pytorch_msssim asserts side > 96).
+        ``n_valid`` < B: only the first n_valid samples of the (padded) batch count -- a smaller test batch evaluated on the
+        training engine's buffers instead of re-binding the whole engine to its size; every sample is independent on this path
+        (no batch norm), so the padded rows change nothing in the first n_valid."""
         o, C, B = self.ops, self.C, self.B
+        n = B if n_valid is None else int(n_valid)
+        assert 1 <= n <= B
         fake = self.G.forward(coarse, save=False)
         m = self.scal[5:8]
         m.zero_()
-        o.l1(fine, fake, m[0:1])
-        o.sqdiff(fine, fake, m[1:2])
+        o.l1(fine[:n], fake[:n], m[0:1])
+        o.sqdiff(fine[:n], fake[:n], m[1:2])
         out = C.forward(fine)
-        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
+        o.sum_strided(out, n, out.stride(0), 1.0 / n, self._sc("c_real_mean"))
         out = C.forward(fake)
-        o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
+        o.sum_strided(out, n, out.stride(0), 1.0 / n, self._sc("c_fake_mean"))
         s = self.scal.detach().cpu().tolist()
         d = {"l1_sum": s[5], "sq_sum": s[6], "c_real_mean": s[0], "c_fake_mean": s[1]}
         if self.dist is not None and self.world > 1:
             d = self.dist.reduce_scalars(d, mean=("c_real_mean", "c_fake_mean"), total=("l1_sum", "sq_sum"))
-        n = self.n_real_elems * self.world
+        cnt = (self.n_real_elems // B) * n * self.world
         msssim = None
         H, W = fine.shape[1], fine.shape[2]
         if min(H, W) > 96:
             if self._msssim is None:
+                self._msssim = {}
+            if n not in self._msssim:
                 from .msssim import MsSsim
-                self._msssim = MsSsim(o, B, H, W, c_real=self.G.npred)
-            msssim = self._msssim(fine, fake, dist=self.dist, world=self.world)
-        return {"MAE": d["l1_sum"] / n, "MSE": d["sq_sum"] / n, "Wass": d["c_real_mean"] - d["c_fake_mean"], "MSSSIM": msssim}
+                self._msssim[n] = MsSsim(o, n, H, W, c_real=self.G.npred)
+            msssim = self._msssim[n](fine[:n], fake[:n], dist=self.dist, world=self.world)
+        return {"MAE": d["l1_sum"] / cnt, "MSE": d["sq_sum"] / cnt, "Wass": d["c_real_mean"] - d["c_fake_mean"], "MSSSIM": msssim}
 
     _msssim = None
 

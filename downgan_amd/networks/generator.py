@@ -46,13 +46,6 @@ class Generator(NativeModule):
             native.load_state_dict(self.state_dict())
         self._bound = native
 
-    def unbind(self):
-        """Take the parameters back (host copy) and drop the reference to the engine's network, so its buffers can be freed."""
-        if self._bound is not None:
-            self._sd = self._bound.state_dict()
-            self._bound = None
-
-    # -- forward --------------------------------------------------------------------------------------
     def _get(self, B, S):
         if self._bound is not None and (self._bound.B, self._bound.S) == (B, S):
             return self._bound

@@ -62,6 +62,29 @@ def pix_layout(t):
     return ld, n * h * w
 
 
+# The deterministic-mode workspace is ONE per process, like the library's switch (csrc/debug.hip): every HipOps(deterministic=True)
+# holds a reference; the buffer is registered once and deregistered when the last holder closes -- a process normally has several
+# op objects alive (the losses' cache, the network modules, one per engine re-bind), and collecting an old one must not switch the
+# mode off under the live engine.
+_DET = {"ws": None, "refs": 0}
+
+
+def _det_acquire(lib, device, nbytes):
+    if _DET["ws"] is None or _DET["ws"].numel() < nbytes or _DET["ws"].device != torch.device(device):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)          # nothing in flight may still be writing partials into the buffer being replaced
+        check(lib.dg_set_deterministic_workspace(C.c_void_p(ws.data_ptr()), ws.numel()), "dg_set_deterministic_workspace")
+        _DET["ws"] = ws
+    _DET["refs"] += 1
+
+
+def _det_release(lib):
+    _DET["refs"] = max(0, _DET["refs"] - 1)
+    if _DET["refs"] == 0 and _DET["ws"] is not None:
+        lib.dg_set_deterministic_workspace(C.c_void_p(0), 0)
+        _DET["ws"] = None
+
+
 class HipOps:
     """The HIP backend.  ``dtype`` is the storage/compute precision of activations and weight packs."""
 
@@ -71,8 +94,9 @@ class HipOps:
         """``deterministic`` (default: the environment variable DG_DETERMINISTIC): run-to-run bit-identical results.  The split-K
         weight gradients and the small reductions accumulate with fp32 atomics whose order varies between runs; in this mode they
         write their partials into a workspace this object owns (``det_workspace_mb``) and add them in a fixed order
-        (csrc/debug.hip, dg_set_deterministic_workspace).  The switch is process-wide in the library: the last HipOps created with
-        ``deterministic=True`` owns it until ``close()`` / garbage collection.
+        (csrc/debug.hip, dg_set_deterministic_workspace).  The switch is process-wide in the library: the workspace is shared and
+        reference-counted over all HipOps created with ``deterministic=True``; the mode ends when the last of them is closed /
+        collected.  ``ops.deterministic`` reads the library's state.
 
         ``f8_critic``: MXFP8 conv path (BASELINE configs[4]) -- forward and data-gradient convs of critic layers whose
         reduction channels are a multiple of 128 run on the block-scaled fp8 MFMA: their bf16 source tensor and weight pack are
@@ -95,18 +119,24 @@ class HipOps:
         self._f8_scratch = {}
         if deterministic is None:
             deterministic = os.environ.get("DG_DETERMINISTIC", "0") not in ("", "0")
-        self.deterministic = bool(deterministic)
-        self._det_ws = None
-        if self.deterministic:
-            self._det_ws = torch.empty(int(det_workspace_mb) << 20, dtype=torch.uint8, device=self.device)
-            check(self.lib.dg_set_deterministic_workspace(C.c_void_p(self._det_ws.data_ptr()), self._det_ws.numel()), "dg_set_deterministic_workspace")
+        self._det_held = False
+        if deterministic:
+            _det_acquire(self.lib, self.device, int(det_workspace_mb) << 20)
+            self._det_held = True
         self._finite_counts = None
 
+    @property
+    def deterministic(self):
+        """Whether the LIBRARY is in deterministic mode: the switch is process-wide, so an op object created without the flag
+        is deterministic too while any other holds the workspace."""
+        return bool(self.lib.dg_deterministic())
+
     def close(self):
-        """Give the library's deterministic-mode workspace back (no-op otherwise)."""
-        if self._det_ws is not None:
-            self.lib.dg_set_deterministic_workspace(C.c_void_p(0), 0)
-            self._det_ws = None
+        """Drop this object's reference to the deterministic-mode workspace (no-op otherwise); the library leaves the mode when
+        the last holder has gone."""
+        if self._det_held:
+            self._det_held = False
+            _det_release(self.lib)
 
     def __del__(self):
         try:

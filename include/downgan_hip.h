@@ -157,6 +157,11 @@ int dg_last_conv_kernels(void);
  * Returns the number of descriptors written to out[0..3], or a negative dg_status. */
 int dg_conv3x3_plan(const dg_conv_geom* g, int kind, dg_gg_desc* out);
 
+/* Host-only: how dg_conv3x3_dgrad launches geometry g -- 1 = the four parity classes of a stride-2 layer merged into one launch
+ * of the halo kernel (or a stride-1 layer's single class), 4 = one launch per class (narrow layers, or rows too long for the halo
+ * kernel's 24-bit row step), negative = dg_status. */
+int dg_conv3x3_dgrad_launches(const dg_conv_geom* g);
+
 /* Derives the compute-precision weight packs from the fp32 MASTER, which is kept forward-packed and
  * padded as [CoutP][9][CinP] (tap = r*3+s; for a pixel-shuffle layer the host has already moved
  * output channel co=4c+2i+j to row (2i+j)*Cout/4 + c, torch PixelShuffle order, generator.py:73):

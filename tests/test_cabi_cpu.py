@@ -174,3 +174,18 @@ def test_hip_runtime_binding_is_checked_in_both_load_orders():
         if bad.returncode == 0:       # this torch build resolved to the same runtime object: nothing to complain about
             continue
         assert "RuntimeError" in bad.stderr and "two HIP runtimes in one process" in bad.stderr, (first, bad.stderr[-600:])
+
+
+def test_merged_stride2_dgrad_respects_the_halo_row_step_limit():
+    """A stride-2 data gradient runs as ONE merged launch of the halo kernel (conv_halo.hip, SEG) -- unless a source row is too long
+    for that kernel's 24-bit row-step multiplies (Wo * Cout * elemsize >= 8 MiB): then the planner must keep the four per-class
+    descriptors, which the row-tiled kernel understands, instead of handing it the merged one (it would write one class only)."""
+    lib = _lib.lib()
+    geom = lambda **kw: _lib.ConvGeom(**dict(dict(dtype=_lib.DG_BF16, N=1, H=64, W=64, Cin=128, Cout=128, stride=2, cin_real=0,
+                                                   pixel_shuffle=0, ldx=128, ldy=128), **kw))
+    assert lib.dg_conv3x3_dgrad_launches(C.byref(geom())) == 1
+    assert lib.dg_conv3x3_dgrad_launches(C.byref(geom(stride=1))) == 1
+    assert lib.dg_conv3x3_dgrad_launches(C.byref(geom(Cin=16, ldx=16))) == 4                         # narrow dx: per-class launches
+    assert lib.dg_conv3x3_dgrad_launches(C.byref(geom(W=8190, Cout=1024, ldy=1024))) == 1            # 4095 * 1024 * 2 < 8 MiB
+    assert lib.dg_conv3x3_dgrad_launches(C.byref(geom(W=8192, Cout=1024, ldy=1024))) == 4            # 4096 * 1024 * 2 = 8 MiB
+    assert lib.dg_conv3x3_dgrad_launches(C.byref(geom(dtype=_lib.DG_F32, W=4096, Cout=1024, ldy=1024))) == 4

@@ -127,3 +127,21 @@ def test_check_finite_raises_on_the_gpu_path():
     eng.C.load_state_dict(bad)
     with pytest.raises(FloatingPointError, match="critic iteration"):
         eng.critic_iteration(xc, xf, alpha, apply_update=False)
+
+
+def test_deterministic_workspace_is_shared_and_reference_counted():
+    """The mode is process-wide in the library; a process holds several op objects (the losses' cache, the modules, one per engine
+    re-bind).  Collecting an EARLIER deterministic object must not switch the mode off under a live one (round-3 advice): the
+    workspace is one per process, released by its last holder, and ``ops.deterministic`` reads the library's state."""
+    from downgan_amd import ops as ops_mod
+    plain = HipOps("bf16", deterministic=False)
+    assert not plain.deterministic
+    a = HipOps("bf16", deterministic=True, det_workspace_mb=4)
+    ws = ops_mod._DET["ws"].data_ptr()
+    b = HipOps("bf16", deterministic=True, det_workspace_mb=4)
+    assert ops_mod._DET["ws"].data_ptr() == ws and ops_mod._DET["refs"] >= 2
+    assert a.deterministic and b.deterministic and plain.deterministic         # the library's switch, whoever asks
+    del a                                                                       # the earlier object goes first
+    assert b.deterministic and ops_mod._DET["ws"] is not None
+    b.close(); b.close()                                                        # idempotent
+    assert not b.deterministic and not plain.deterministic

@@ -102,6 +102,9 @@ def test_bench_self_launch_rehearsal_line():
     assert len({r["pid"] for r in d["ranks_seen"]}) == 2
     assert all(math.isfinite(v) for v in d["losses"].values()) and {"critic_loss", "gp_ret", "g_loss"} <= set(d["losses"])
     assert "fp8" not in d and "cpu_baseline" not in d       # single-GPU extras only
+    # every deferred exchange of the timed region was queried for completion before its wait (5 critic + 1 generator updates)
+    ov = d["exchange_overlap"]
+    assert ov["finishes"] == 6 and 0 <= ov["already_complete"] <= ov["finishes"], ov
 
 
 def test_bench_default_line_carries_fp8_and_event_free_numbers():

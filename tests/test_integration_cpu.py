@@ -203,6 +203,56 @@ def test_test_loader_with_another_batch_size_is_evaluated(monkeypatch):
     tr.train(train, test, epochs=1)
     (ep,) = tr.metrics_log
     assert ep["test_batches"] == 2 and set(ep["test"]) >= {"MAE", "MSE", "Wass"}
-    assert tr._engine.C.P.t == 1                                                   # the test pass re-bound the engine, the optimizer state survived
+    # the ragged test batch (1 sample) ran PADDED on the training engine's buffers: no re-bind, the optimizer state untouched
+    assert tr._engine.B == 2 and tr._engine.C.P.t == 1
+    padded = tr.gen_batch_and_log_metrics(tc[4:], tf[4:])
+    assert tr._engine.B == 2
+    tr._eng(tc[4:], tf[4:])                                                        # the same batch on an engine of its own size
+    assert tr._engine.B == 1 and tr._engine.C.P.t == 1
+    own = tr.gen_batch_and_log_metrics(tc[4:], tf[4:])
+    for k in ("MAE", "MSE", "Wass", "MSSSIM"):
+        assert own[k] is not None and abs(padded[k] - own[k]) <= 1e-5 * max(abs(own[k]), 1e-3), (k, padded[k], own[k])
+    # a LARGER batch still re-binds (its MS-SSIM normalisation spans the whole batch)
+    tr.gen_batch_and_log_metrics(tc[:3], tf[:3])
+    assert tr._engine.B == 3 and tr._engine.C.P.t == 1
     with pytest.raises(ValueError):
         tr.train(train, torch.utils.data.DataLoader(NetCDFSR(tc[:0], tf[:0]), batch_size=2), epochs=1)
+
+
+def test_failed_rebind_restores_the_running_engine(monkeypatch):
+    """If the engine for a new batch size cannot be built (out of memory at 142 GiB, an unsupported shape), the parameters and Adam
+    state -- which live only in the carried device buffers at that moment -- go back into an engine of the size that was running:
+    state_dict() / checkpoints keep seeing the TRAINED weights (round-3 advice), and the error reaches the caller."""
+    from downgan_amd import backend, synthetic
+    from downgan_amd.GAN import losses
+    from downgan_amd.GAN.wasserstein import WassersteinGAN
+    from downgan_amd.networks.critic import Critic
+    from downgan_amd.networks.generator import Generator
+    from oracle.emu_ops import EmuOps
+    import downgan_amd.config.hyperparams as hp
+    monkeypatch.setattr(backend, "make_ops", lambda dtype, device: EmuOps("f32"))
+    monkeypatch.setattr(losses, "_ops", {})
+    monkeypatch.setattr(hp, "batch_size", 2)
+    torch.set_num_threads(4)
+    coarse, fine = synthetic.tiles(5, 2, 16, seed=9)
+    tc, tf = torch.from_numpy(coarse), torch.from_numpy(fine)
+    G, C = Generator(16, 128, 2, 2, num_res_blocks=1), Critic(16, 128, 2)
+    sd_init = C.state_dict()
+    tr = WassersteinGAN(G, C)
+    tr._critic_train_iteration(tc[:2], tf[:2], alpha=torch.from_numpy(synthetic.alpha(2, 0)))
+    trained = C.state_dict()
+    assert any(not torch.equal(trained[k], sd_init[k]) for k in trained)
+    real_build = tr._build
+
+    def failing(B, cin, S, carry):
+        if B == 3:
+            raise MemoryError("no room for the batch-3 engine")
+        return real_build(B, cin, S, carry)
+    monkeypatch.setattr(tr, "_build", failing)
+    with pytest.raises(MemoryError):
+        tr._critic_train_iteration(tc[:3], tf[:3], alpha=torch.from_numpy(synthetic.alpha(3, 1)))
+    assert tr._engine is not None and tr._engine.B == 2 and tr._engine.C.P.t == 1
+    after = C.state_dict()
+    assert all(torch.equal(after[k], trained[k]) for k in trained)                 # not the initial weights
+    tr._critic_train_iteration(tc[:2], tf[:2], alpha=torch.from_numpy(synthetic.alpha(2, 1)))     # and training goes on
+    assert tr._engine.C.P.t == 2

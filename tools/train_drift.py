@@ -37,8 +37,8 @@ def learnable_batch(B, cin, S, step):
     return c, (fine + torch.from_numpy(pattern)[None]).numpy().astype(np.float32)
 
 
-def run(mode, steps, B, S, F_, cin, nrb):
-    ops = HipOps("f32" if mode == "f32" else "bf16", "cuda:0", f8_critic=mode == "fp8", f8_generator=mode == "fp8")
+def run(mode, steps, B, S, F_, cin, nrb, deterministic=None):
+    ops = HipOps("f32" if mode == "f32" else "bf16", "cuda:0", f8_critic=mode == "fp8", f8_generator=mode == "fp8", deterministic=deterministic)
     eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B), num_res_blocks=nrb)
     eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))
     eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
