@@ -9,7 +9,7 @@
 // shifted row; only the weights stream per tap-step.
 #ifdef DG_STAMP
 // diagnostic build only (make stamp): per-wave cycle sums of the segments of a tap-step, blocks 0/1
-__device__ unsigned long long g_stamps[2 * 8 * 8];
+__device__ unsigned long long g_stamps[2 * 8 * 12];
 extern "C" int dg_debug_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
 }
@@ -265,6 +265,75 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
   int pa = 0;
   read_frags(fa, fb, pa, pb, 0);
   STAMP(tL0);
+#ifdef DG_MIDBAR
+  // ONE barrier per step, between the two k-blocks.  By the end of k-block 0 a wave holds every fragment of k-block 1 in registers
+  // (the progressive re-read), so after the barrier nobody reads slot s&1 any more: W[s+2] may be DMA-ed into it, W[s+1] (whose
+  // pieces every wave waited for in front of the barrier) is visible, and k-block 1's MFMAs run with the SAME progressive re-read
+  // pulling step s+1's first weight fragments out of the other slot, one DMA piece behind each MFMA row pair.  What is left
+  // without MFMAs in flight is two reads of four pixel fragments and the barrier (the end-of-step schedule had the twelve
+  // fragment reads of the next step and the four DMA issues there: ~760 of 2690 cycles per step).
+  for (int s = 0; s < nsteps; ++s) {
+    STAMP(tA);
+    const bool more = s + 1 < nsteps;
+    int ntap = tap + 1, ncbn = cb;
+    const int ntaps_cb = ntaps_of(cb);
+    if (ntap == ntaps_cb) { ntap = 0; ncbn = cb + 1; }
+    const bool swap = ntap == 0 && more;
+    const bool patch_now = cb + 1 < ncb && (ntaps_cb == 1 || tap == 0);
+    const bool fetch = s + 2 < nsteps;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mma_rows(fa, fb, 2 * q);
+      asm volatile("" : "+v"(acc[2 * q][0]), "+v"(acc[2 * q][1]), "+v"(acc[2 * q][2]), "+v"(acc[2 * q][3]),
+                        "+v"(acc[2 * q + 1][0]), "+v"(acc[2 * q + 1][1]), "+v"(acc[2 * q + 1][2]), "+v"(acc[2 * q + 1][3]) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      fa[2 * q] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q) * 16 * WROW);
+      fa[2 * q + 1] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q + 1) * 16 * WROW);
+      asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    if (patch_now) load_patch(cb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(tB);
+    // every LDS read of this step is in registers (the barrier's lgkmcnt(0)); own pieces of W[s+1] have landed (vmcnt)
+    if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
+    STAMP(tC);
+    if (swap) store_patch();             // channel-block boundary: the single-buffered patch is rewritten (nobody reads it any more) ...
+    const int pan = ((s + 1) & 1) * (BC * WROW);
+    // (the re-read also runs in the last step, into fragments nobody uses: no branch around LDS reads)
+    if (fetch) dma_setup(cbw, tapw, s & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mma_rows(fa, fb, 2 * q);
+      asm volatile("" : "+v"(acc[2 * q][0]), "+v"(acc[2 * q][1]), "+v"(acc[2 * q][2]), "+v"(acc[2 * q][3]),
+                        "+v"(acc[2 * q + 1][0]), "+v"(acc[2 * q + 1][1]), "+v"(acc[2 * q + 1][2]), "+v"(acc[2 * q + 1][3]) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      fa[2 * q] = *reinterpret_cast<const uint4*>(fa_k[0] + pan + (2 * q) * 16 * WROW);
+      fa[2 * q + 1] = *reinterpret_cast<const uint4*>(fa_k[0] + pan + (2 * q + 1) * 16 * WROW);
+      asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+      if (fetch) dma_piece(q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    adv(cbw, tapw);
+    STAMP(tD);
+    if (swap) __syncthreads();           // ... and published (LDS writes only: the DMA pieces just issued stay in flight)
+    pa = pan;
+    pb = patch_ptr(ncbn < ncb ? ncbn : 0, ntap);
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tap = ntap; cb = ncbn;
+    STAMP(tE);
+#ifdef DG_STAMP
+    sAB += tB - tA; sBC += tC - tB; sCD += tD - tC; sDE += tE - tD;
+#endif
+  }
+#else
   for (int s = 0; s < nsteps; ++s) {
     STAMP(tA);
     const bool more = s + 1 < nsteps;
@@ -324,12 +393,18 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
     sAB += tB - tA; sBC += tC - tB; sCD += tD - tC; sDE += tE - tD;
 #endif
   }
+#endif
 #ifdef DG_STAMP
   unsigned long long tL1, tX;
   STAMP(tL1);
 #endif
+#ifdef DG_STAMP
+  unsigned long long est[4] = {0, 0, 0, 0};
+  halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, SEG ? cls >> 1 : -1, SEG ? cls & 1 : -1, est);
+#else
   if constexpr (SEG) halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, cls >> 1, cls & 1);
   else halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
+#endif
 #ifdef DG_STAMP
   STAMP(tX);
   if (blockIdx.x < DG_WGLOG_MAX && tid == 0) {
@@ -342,8 +417,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
   // two workgroups from the MIDDLE of the launch (steady state: the first round starts in lock-step and runs ~25 % faster per step)
   const unsigned sb = blockIdx.x - a.nwg / 2;
   if (sb < 2u && lane == 0) {
-    unsigned long long* o = g_stamps + (sb * 8 + wave) * 8;
+    unsigned long long* o = g_stamps + (sb * 8 + wave) * 12;
     o[0] = sAB; o[1] = sBC; o[2] = sCD; o[3] = sDE; o[4] = (unsigned long long)nsteps; o[5] = tL1 - tL0; o[6] = tX - tL1; o[7] = tL0 - tK0;
+    o[8] = est[0] - tL1; o[9] = est[1] - est[0]; o[10] = est[2] - est[1]; o[11] = est[3] - est[2];
   }
 #endif
 }
@@ -357,6 +433,15 @@ static int gg_launch_halo4w(GGArgs& a, int N, hipStream_t st) {
   a.nct = (unsigned)((a.Nout + BC - 1) / BC);
   a.nwg = a.nct * (unsigned)(tiles_x * tiles_y * N) * (SEG ? 4u : 1u);
   g_last_kinds |= 8;
+#ifdef DG_STAMP
+  static const int abl = getenv("DG_ABL") ? atoi(getenv("DG_ABL")) : 0;
+  a.dbg = abl;
+  if (abl & 2) {        // one workgroup per CU: no partner on the CU's vector-memory pipe / matrix pipe
+    hipFuncSetAttribute((const void*)&gg_halo4w_kernel<T, S2, PS, NW, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipLaunchKernelGGL((gg_halo4w_kernel<T, S2, PS, NW, SEG>), dim3(a.nwg), dim3(64 * NW), 100 * 1024, st, a, tiles_x, tiles_y);
+    return dg_check_launch();
+  }
+#endif
   hipLaunchKernelGGL((gg_halo4w_kernel<T, S2, PS, NW, SEG>), dim3(a.nwg), dim3(64 * NW), LDS_BYTES, st, a, tiles_x, tiles_y);
   return dg_check_launch();
 }

@@ -55,6 +55,7 @@ struct GGArgs {
   unsigned nwg, nct;
   int mask_c0, mask_last;                      // dg_epilogue: mask for channels >= mask_c0 only, applied after the accumulate
   int seg;                                     // 1: the four parity classes of a stride-2 data gradient in ONE launch (conv_halo.hip, SEG)
+  int dbg;                                     // diagnostic (stamp) builds only: ablation bits from DG_ABL (1: epilogue stores dropped, 2: one workgroup per CU)
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -436,8 +437,14 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
 // data-gradient launch, conv_halo.hip SEG).
 template <typename T, int NH>
 __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 * NH][4], int img, int ty0, int tx0, int c0, int wp,
-                                              int wc, int l15, int g, int oy_o = -1, int ox_o = -1) {
+                                              int wc, int l15, int g, int oy_o = -1, int ox_o = -1, unsigned long long* est = nullptr) {
+#ifdef DG_STAMP
+#define EPI_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); est[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define EPI_STAMP(i) do { } while (0)
+#endif
   constexpr int ES = (int)sizeof(T);
+  EPI_STAMP(0);
   const int psm = a.dst_ps ? 2 : a.dy_mul, psx = a.dst_ps ? 2 : a.dx_mul;
   const int oy = oy_o >= 0 ? oy_o : (a.dst_ps ? 0 : a.dy_off), ox = ox_o >= 0 ? ox_o : (a.dst_ps ? 0 : a.dx_off);
   // workgroup base pixel (scalar) and this lane's relative pixel for tile row wp*4 (+ i rows of pitch `rowp`)
@@ -454,7 +461,11 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
   R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
   R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.ldqs, 1);
   R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
+#ifdef DG_STAMP
+  const bool xok = tx0 + l15 < a.Wg && !(a.dbg & 1);       // ablation: every epilogue store (and operand load) out of range = dropped
+#else
   const bool xok = tx0 + l15 < a.Wg;
+#endif
   // every mask word of the wave's tile first (NH halves x 4 rows), before the first store
   unsigned mbv[NH][4];
 #pragma unroll
@@ -466,6 +477,7 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       mbv[h][i] = epi64_bits<false>(a, R, ok ? (unsigned)(((rel0 + i * rowp) * ldb + (cb64 >> 6) * 4 + g) * 2) : DG_OOB_OFF);
     }
   }
+  EPI_STAMP(1);
   auto run = [&](auto tag, auto htag) {
   constexpr int F = decltype(tag)::value;
   constexpr int h = decltype(htag)::value;          // compile-time: acc[] must never be indexed dynamically
@@ -522,7 +534,10 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
     }
   };
   dispatch(std::integral_constant<int, 0>{});
+  EPI_STAMP(2);
   if constexpr (NH == 2) dispatch(std::integral_constant<int, 1>{});
+  EPI_STAMP(3);
+#undef EPI_STAMP
 }
 
 struct F8Args { const unsigned char* xs; const unsigned char* ws; int ldxs; };   // ldxs: scale bytes per source pixel (Cred/32 unless the source is a slab slice); weights: 9*Cred/32 per row

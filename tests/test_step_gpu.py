@@ -231,18 +231,21 @@ def test_bf16_learning_curve_tracks_fp32_on_a_learnable_task():
     profiles/train_drift_learnable.json).  On the benchmark's pure-noise tiles the step is chaotic and no such comparison exists.
 
     The critic loss swings over +-600 in these steps and crosses zero (..., 640, -282, -110, -14, 28, ...), so a relative bound alone
-    fails near the crossing.  The yardstick for the absolute part is MEASURED here, not typed in: the fp32 mode is run three times --
-    twice as it is (the order of its fp32 atomics differs from run to run) and once in deterministic mode (index-ordered reductions)
-    -- and bf16 may be off by max(2 % of the value, 10 x the spread of the three fp32 runs at that step, 10 x their median spread
-    over the compared steps).  All four curves go to gpurun_out/learning_curve_yardstick.json."""
+    fails near the crossing.  The yardsticks for the absolute part are MEASURED here, not typed in.  (i) The fp32 mode is run three
+    times -- twice as it is (the order of its fp32 atomics differs from run to run) and once in deterministic mode (index-ordered
+    reductions): their spread is what 1e-7-sized disturbances grow to (recorded on MI355X: 4e-5 at step 2, 1e-2 at step 8, 9e-2 at
+    the +640 peak).  (ii) The fp32 mode once more with its INITIAL parameters rounded to bf16: what ONE bf16-sized disturbance grows
+    to.  bf16, which rounds weights and activations at every step, may be off by max(2 % of the value, 10 x the fp32 spread at that
+    step, 3 x the deviation of the rounded-start fp32 run at that step).  All five curves go to
+    gpurun_out/learning_curve_yardstick.json."""
     import importlib.util
-    import statistics
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("train_drift", os.path.join(root, "tools", "train_drift.py"))
     td = importlib.util.module_from_spec(spec); spec.loader.exec_module(td)
     cfg = dict(steps=30, B=4, S=32, F_=128, cin=2, nrb=2)
     runs = {"f32_a": td.summarise(td.run("f32", **cfg)), "f32_b": td.summarise(td.run("f32", **cfg)),
-            "f32_deterministic": td.summarise(td.run("f32", deterministic=True, **cfg)), "bf16": td.summarise(td.run("bf16", **cfg))}
+            "f32_deterministic": td.summarise(td.run("f32", deterministic=True, **cfg)),
+            "f32_rounded_start": td.summarise(td.run("f32", round_init=True, **cfg)), "bf16": td.summarise(td.run("bf16", **cfg))}
     a = [v for _, v in runs["f32_a"]["content_loss_generator_steps"]]
     b = [v for _, v in runs["bf16"]["content_loss_generator_steps"]]
     assert len(a) == 6 and all(abs(x - y) <= 5e-3 * x for x, y in zip(a, b)), (a, b)
@@ -250,21 +253,23 @@ def test_bf16_learning_curve_tracks_fp32_on_a_learnable_task():
     f32 = [runs[k]["critic_loss"][:n] for k in ("f32_a", "f32_b", "f32_deterministic")]
     cl16 = runs["bf16"]["critic_loss"][:n]
     spread = [max(c) - min(c) for c in zip(*f32)]
-    floor = 10 * statistics.median(spread)
-    bound = [max(2e-2 * abs(x), 10 * sp, floor) for x, sp in zip(f32[0], spread)]
+    one_rounding = [abs(x - y) for x, y in zip(f32[0], runs["f32_rounded_start"]["critic_loss"][:n])]
+    bound = [max(2e-2 * abs(x), 10 * sp, 3 * dv) for x, sp, dv in zip(f32[0], spread, one_rounding)]
     diff = [abs(x - y) for x, y in zip(f32[0], cl16)]
     try:
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "learning_curve_yardstick.json"), "w") as f:
             json.dump({"what": "critic loss of the first 10 steps of the learnable task: fp32 mode twice, fp32 deterministic mode, bf16; "
-                               "spread = max - min of the three fp32 runs per step; bound = max(2e-2 |x|, 10 spread, 10 median spread)",
+                               "fp32 with bf16-rounded initial parameters; spread = max - min of the three plain fp32 runs per step; "
+                               "bound = max(2e-2 |x|, 10 spread, 3 |f32_rounded_start - f32_a|)",
                        "config": cfg, "critic_loss": {k: v["critic_loss"][:n] for k, v in runs.items()}, "spread_f32": spread,
-                       "bf16_minus_f32": diff, "bound": bound,
+                       "f32_rounded_start_minus_f32": one_rounding, "bf16_minus_f32": diff, "bound": bound,
                        "content_loss_generator_steps": {k: v["content_loss_generator_steps"] for k, v in runs.items()}}, f, indent=1)
     except OSError:
         pass
-    print("learning-curve yardstick: fp32 spread", [f"{s:.2e}" for s in spread], "bf16 - fp32", [f"{d:.2e}" for d in diff])
-    assert all(d <= bd for d, bd in zip(diff, bound)), (diff, bound, spread)
+    print("learning-curve yardstick: fp32 spread", [f"{s:.2e}" for s in spread], "one rounding", [f"{d:.2e}" for d in one_rounding],
+          "bf16 - fp32", [f"{d:.2e}" for d in diff])
+    assert all(d <= bd for d, bd in zip(diff, bound)), (diff, bound, spread, one_rounding)
 
 
 def test_hip_graph_replay_equals_eager():

@@ -30,13 +30,21 @@ for name, N, H, ci, co, st, op in CASES:
         for _ in range(3):
             o.conv_fwd(cv, x, w, y, act=0.2)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    if op.startswith("dgrad"):
+        o.conv_dgrad(cv, dy, w, dx, **kw)
+    else:
+        o.conv_fwd(cv, x, w, y, act=0.2)
+    e1.record(); torch.cuda.synchronize()
+    name = f"{name}  [{e0.elapsed_time(e1):.3f} ms, {o.conv_flops(cv) / e0.elapsed_time(e1) / 1e9:.0f} TFLOP/s, DG_ABL={os.environ.get('DG_ABL', '0')}]"
     buf = (C.c_ulonglong * 512)()
     o.lib.dg_debug_stamps.argtypes = [C.c_void_p]
     assert o.lib.dg_debug_stamps(buf) == 0
     print(name)
     for b in range(2):
         for wv in range(4):
-            v = [buf[(b * 8 + wv) * 8 + k] for k in range(8)]
+            v = [buf[(b * 8 + wv) * 12 + k] for k in range(12)]
             n = max(v[4], 1)
             print(f"  blk {b} wave {wv}: steps {v[4]:3d}  per-step cycles: mma(k0)+reads k1 {v[0]/n:6.0f}  mma(k1) {v[1]/n:6.0f}  barrier {v[2]/n:6.0f}  reads k0'+DMA {v[3]/n:6.0f}"
-                  f"  sum {sum(v[:4])/n:6.0f} | prologue {v[7]:7d}  loop {v[5]:8d}  epilogue {v[6]:7d}")
+                  f"  sum {sum(v[:4])/n:6.0f} | prologue {v[7]:7d}  loop {v[5]:8d}  epilogue {v[6]:7d} = entry {v[8]} + setup/mask loads {v[9]} + half 0 {v[10]} + half 1 {v[11]}")

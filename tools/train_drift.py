@@ -37,11 +37,15 @@ def learnable_batch(B, cin, S, step):
     return c, (fine + torch.from_numpy(pattern)[None]).numpy().astype(np.float32)
 
 
-def run(mode, steps, B, S, F_, cin, nrb, deterministic=None):
+def run(mode, steps, B, S, F_, cin, nrb, deterministic=None, round_init=False):
+    """``round_init``: the initial parameters rounded to bf16 ONCE (a perturbation of relative size 2^-9, the size of one bf16
+    rounding) -- run in fp32 mode it shows how far a single bf16-sized disturbance moves the trajectory: the yardstick for what
+    the bf16 mode, which rounds weights and activations at every step, may differ by."""
     ops = HipOps("f32" if mode == "f32" else "bf16", "cuda:0", f8_critic=mode == "fp8", f8_generator=mode == "fp8", deterministic=deterministic)
     eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B), num_res_blocks=nrb)
-    eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))
-    eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
+    rnd = (lambda d: {k: torch.from_numpy(v).to(torch.bfloat16).to(torch.float32) for k, v in d.items()}) if round_init else (lambda d: d)
+    eng.G.load_state_dict(rnd(synthetic.generator_params(F_, cin, 2, nrb)))
+    eng.C.load_state_dict(rnd(synthetic.critic_params(F_, 8 * S, 2)))
     xc, xf = ops.zeros(B, S, S, eng.G.cin_p), ops.zeros(B, 8 * S, 8 * S, eng.G.np_p)
     out = []
     for s in range(steps):
