@@ -217,11 +217,18 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
   auto barrier_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
   auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPL) : "memory"); __syncthreads(); };
 
+  constexpr bool PREB = sizeof(T) == 2;      // (the fp32 parity instances keep the bias in the epilogue: 28 -> 192 B of scratch otherwise)
+  // accumulators start at the bias (acc[4h + q][.][e] = channel c0 + wh*128 + 64h + 16g + 4q + e, the epilogue's perm64 order):
+  // its loads ride behind the first patch instead of costing every tile's epilogue a global round trip per 64-channel half
   f32x4_t acc[8][4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < 8; ++j) {
+    f32x4_t b = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int cbq = c0 + (tid >> 8) * 128 + (j >> 2) * 64 + 16 * ((tid & 63) >> 4) + 4 * (j & 3);
+    if (PREB && a.bias && cbq < a.Nout) { const float4 b4 = *reinterpret_cast<const float4*>(a.bias + cbq); b = f32x4_t{b4.x, b4.y, b4.z, b4.w}; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[j][i] = b;
+  }
 
   const char* fa_k[2];
 #pragma unroll
@@ -265,75 +272,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
   int pa = 0;
   read_frags(fa, fb, pa, pb, 0);
   STAMP(tL0);
-#ifdef DG_MIDBAR
-  // ONE barrier per step, between the two k-blocks.  By the end of k-block 0 a wave holds every fragment of k-block 1 in registers
-  // (the progressive re-read), so after the barrier nobody reads slot s&1 any more: W[s+2] may be DMA-ed into it, W[s+1] (whose
-  // pieces every wave waited for in front of the barrier) is visible, and k-block 1's MFMAs run with the SAME progressive re-read
-  // pulling step s+1's first weight fragments out of the other slot, one DMA piece behind each MFMA row pair.  What is left
-  // without MFMAs in flight is two reads of four pixel fragments and the barrier (the end-of-step schedule had the twelve
-  // fragment reads of the next step and the four DMA issues there: ~760 of 2690 cycles per step).
-  for (int s = 0; s < nsteps; ++s) {
-    STAMP(tA);
-    const bool more = s + 1 < nsteps;
-    int ntap = tap + 1, ncbn = cb;
-    const int ntaps_cb = ntaps_of(cb);
-    if (ntap == ntaps_cb) { ntap = 0; ncbn = cb + 1; }
-    const bool swap = ntap == 0 && more;
-    const bool patch_now = cb + 1 < ncb && (ntaps_cb == 1 || tap == 0);
-    const bool fetch = s + 2 < nsteps;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      mma_rows(fa, fb, 2 * q);
-      asm volatile("" : "+v"(acc[2 * q][0]), "+v"(acc[2 * q][1]), "+v"(acc[2 * q][2]), "+v"(acc[2 * q][3]),
-                        "+v"(acc[2 * q + 1][0]), "+v"(acc[2 * q + 1][1]), "+v"(acc[2 * q + 1][2]), "+v"(acc[2 * q + 1][3]) :: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      fa[2 * q] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q) * 16 * WROW);
-      fa[2 * q + 1] = *reinterpret_cast<const uint4*>(fa_k[1] + pa + (2 * q + 1) * 16 * WROW);
-      asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH + 64);
-    __builtin_amdgcn_sched_barrier(0);
-    if (patch_now) load_patch(cb + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    STAMP(tB);
-    // every LDS read of this step is in registers (the barrier's lgkmcnt(0)); own pieces of W[s+1] have landed (vmcnt)
-    if (patch_now && !swap) barrier_keep_patch(); else barrier_all();
-    STAMP(tC);
-    if (swap) store_patch();             // channel-block boundary: the single-buffered patch is rewritten (nobody reads it any more) ...
-    const int pan = ((s + 1) & 1) * (BC * WROW);
-    // (the re-read also runs in the last step, into fragments nobody uses: no branch around LDS reads)
-    if (fetch) dma_setup(cbw, tapw, s & 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      mma_rows(fa, fb, 2 * q);
-      asm volatile("" : "+v"(acc[2 * q][0]), "+v"(acc[2 * q][1]), "+v"(acc[2 * q][2]), "+v"(acc[2 * q][3]),
-                        "+v"(acc[2 * q + 1][0]), "+v"(acc[2 * q + 1][1]), "+v"(acc[2 * q + 1][2]), "+v"(acc[2 * q + 1][3]) :: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      fa[2 * q] = *reinterpret_cast<const uint4*>(fa_k[0] + pan + (2 * q) * 16 * WROW);
-      fa[2 * q + 1] = *reinterpret_cast<const uint4*>(fa_k[0] + pan + (2 * q + 1) * 16 * WROW);
-      asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-      if (fetch) dma_piece(q);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    adv(cbw, tapw);
-    STAMP(tD);
-    if (swap) __syncthreads();           // ... and published (LDS writes only: the DMA pieces just issued stay in flight)
-    pa = pan;
-    pb = patch_ptr(ncbn < ncb ? ncbn : 0, ntap);
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(pb + i * PW * PITCH);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    tap = ntap; cb = ncbn;
-    STAMP(tE);
-#ifdef DG_STAMP
-    sAB += tB - tA; sBC += tC - tB; sCD += tD - tC; sDE += tE - tD;
-#endif
-  }
-#else
   for (int s = 0; s < nsteps; ++s) {
     STAMP(tA);
     const bool more = s + 1 < nsteps;
@@ -393,17 +331,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_kernel(const GGArgs a, i
     sAB += tB - tA; sBC += tC - tB; sCD += tD - tC; sDE += tE - tD;
 #endif
   }
-#endif
 #ifdef DG_STAMP
   unsigned long long tL1, tX;
   STAMP(tL1);
 #endif
 #ifdef DG_STAMP
   unsigned long long est[4] = {0, 0, 0, 0};
-  halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, SEG ? cls >> 1 : -1, SEG ? cls & 1 : -1, est);
+  halo_epilogue<T, 2, PREB>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, SEG ? cls >> 1 : -1, SEG ? cls & 1 : -1, est);
 #else
-  if constexpr (SEG) halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, cls >> 1, cls & 1);
-  else halo_epilogue<T, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
+  if constexpr (SEG) halo_epilogue<T, 2, PREB>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, cls >> 1, cls & 1);
+  else halo_epilogue<T, 2, PREB>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
 #endif
 #ifdef DG_STAMP
   STAMP(tX);

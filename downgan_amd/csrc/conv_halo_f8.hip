@@ -217,11 +217,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
   auto barrier_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
   auto barrier_keep_patch = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPL + NPS) : "memory"); __syncthreads(); };   // patch chunks + scale words
 
+  // accumulators start at the bias (conv_halo.hip: its load latency hides in the prologue instead of sitting in every tile's epilogue)
   f32x4_t acc[8][4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < 8; ++j) {
+    f32x4_t b = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int cbq = c0 + (tid >> 8) * 128 + (j >> 2) * 64 + 16 * ((tid & 63) >> 4) + 4 * (j & 3);
+    if (a.bias && cbq < a.Nout) { const float4 b4 = *reinterpret_cast<const float4*>(a.bias + cbq); b = f32x4_t{b4.x, b4.y, b4.z, b4.w}; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[j][i] = b;
+  }
 
   const char* fa_k[2];
 #pragma unroll
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gg_halo4w_f8_kernel(const GGArgs a
     tap = ntap; cb = ncbn;
   }
 #undef F8_FENCE
-  if constexpr (SEG) halo_epilogue<bf16_t, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, cls >> 1, cls & 1);
-  else halo_epilogue<bf16_t, 2>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
+  if constexpr (SEG) halo_epilogue<bf16_t, 2, true>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g, cls >> 1, cls & 1);
+  else halo_epilogue<bf16_t, 2, true>(a, acc, img, ty0, tx0, c0 + wh * 128, wq, 0, l15, g);
 }
 
 template <bool S2, int NW = 4, bool SEG = false>

@@ -435,7 +435,9 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
 // epilogue has no divergent branches.
 // oy_o / ox_o >= 0: destination offsets of this workgroup instead of a.dy_off / a.dx_off (the parity class of a merged stride-2
 // data-gradient launch, conv_halo.hip SEG).
-template <typename T, int NH>
+// PREB: the caller's accumulators were initialised with the bias (the halo kernel loads it in its prologue, where the latency
+// hides behind the first patch; loading it here put one global round trip per 64-channel half into every tile's epilogue).
+template <typename T, int NH, bool PREB = false>
 __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 * NH][4], int img, int ty0, int tx0, int c0, int wp,
                                               int wc, int l15, int g, int oy_o = -1, int ox_o = -1, unsigned long long* est = nullptr) {
 #ifdef DG_STAMP
@@ -455,12 +457,6 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
     return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p) + pb * ld * es), 0, (int)DG_OOB_OFF, 0x00020000);
   };
   const int ldb = (a.Nout >> 6) * 4;
-  EpiRes R;
-  R.rY = rsrc(a.y, a.ldy, ES);
-  R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
-  R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
-  R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.ldqs, 1);
-  R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
 #ifdef DG_STAMP
   const bool xok = tx0 + l15 < a.Wg && !(a.dbg & 1);       // ablation: every epilogue store (and operand load) out of range = dropped
 #else
@@ -468,38 +464,56 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
 #endif
   // every mask word of the wave's tile first (NH halves x 4 rows), before the first store
   unsigned mbv[NH][4];
+  if (a.mask_bits) {
+    const __amdgpu_buffer_rsrc_t rbi = rsrc(a.mask_bits, ldb, 2);
 #pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    const int cb64 = c0 + (wc + h) * 64;
+    for (int h = 0; h < NH; ++h) {
+      const int cb64 = c0 + (wc + h) * 64;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = xok && cb64 + 16 * g < a.Nout && ty0 + wp * 4 + i < a.Hg;
-      mbv[h][i] = epi64_bits<false>(a, R, ok ? (unsigned)(((rel0 + i * rowp) * ldb + (cb64 >> 6) * 4 + g) * 2) : DG_OOB_OFF);
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = xok && cb64 + 16 * g < a.Nout && ty0 + wp * 4 + i < a.Hg;
+        mbv[h][i] = __builtin_amdgcn_raw_buffer_load_b16(rbi, ok ? (unsigned)(((rel0 + i * rowp) * ldb + (cb64 >> 6) * 4 + g) * 2) : DG_OOB_OFF, 0, 0);
+      }
     }
+  } else {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mbv[h][i] = 0u;
   }
   EPI_STAMP(1);
   auto run = [&](auto tag, auto htag) {
   constexpr int F = decltype(tag)::value;
   constexpr int h = decltype(htag)::value;          // compile-time: acc[] must never be indexed dynamically
   {
+    // the descriptors are built HERE, per straight-line instance: each instance computes only the ones its flags read (built
+    // ahead of the dispatch all eight -- 64-bit multiplies each -- sat in front of every epilogue: ~1000 of its ~1800 set-up cycles)
+    EpiRes R;
+    R.rY = rsrc(a.y, a.ldy, ES);
+    R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
+    R.rbi = R.rY; R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
+    R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.ldqs, 1);
+    R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
     // permuted wave tile (perm64): the lane's four channel fragments are the 16 consecutive channels from cb16
     const int cb16 = c0 + (wc + h) * 64 + 16 * g;
     const bool cok = cb16 < a.Nout && xok;
     float bias[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 b4 = (a.bias && cb16 < a.Nout) ? *reinterpret_cast<const float4*>(a.bias + cb16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (!PREB) { if (a.bias && cb16 < a.Nout) b4 = *reinterpret_cast<const float4*>(a.bias + cb16 + 4 * q); }
       bias[4 * q] = b4.x; bias[4 * q + 1] = b4.y; bias[4 * q + 2] = b4.z; bias[4 * q + 3] = b4.w;
     }
     int cc0 = cb16, pj0 = 0;
     if (a.dst_ps) { const int q = cb16 / a.cps_dst; cc0 = cb16 - q * a.cps_dst; pj0 = (q >> 1) * a.Wd + (q & 1); }
     const int bidx = ((c0 + (wc + h) * 64) >> 6) * 4 + g;
+    constexpr int FE = (PREB && F >= 0) ? (F | 512) : F;      // 512: the accumulators already hold the bias
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool ok = cok && ty0 + wp * 4 + i < a.Hg;
       const int rel = rel0 + i * rowp;
       const int pix = rel + pj0;
-      epi64_pixel<T, (F >= 0), F>(a, R, acc[4 * h][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i], bias,
+      epi64_pixel<T, (F >= 0), FE>(a, R, acc[4 * h][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i], bias,
                             ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
                             ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
                             ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[h][i], a.mask && cb16 >= a.mask_c0);
