@@ -216,6 +216,7 @@ def timed_steps(eng, ops, xc, xf, alphas, first, steps, dist, rehearse, kernel_t
     eng.num_steps = -(-eng.num_steps // ci) * ci
     complete_updates()
     if dist:
+        dist.track_overlap()          # count the exchanges of the timed region only (the one just completed belongs to the warm-up)
         dist.barrier()
     torch.cuda.synchronize()
     if kernel_timing:
@@ -364,8 +365,6 @@ def main():
     for s in range(args.warmup):
         eng.train_step(xc, xf, alphas[s])
     gen_steps_timed = -(-args.steps // eng.hp.critic_iterations)
-    if dist:
-        dist.track_overlap()                  # count from the timed region on
     elapsed, prof = timed_steps(eng, ops, xc, xf, alphas, args.warmup, args.steps, dist, args.rehearse_on_one_gpu,
                                 not args.no_kernel_timing, args.per_layer)
     overlap = dict(dist.overlap) if dist else None

@@ -52,16 +52,31 @@ def test_deterministic_mode_is_bit_identical_between_runs(cfg):
 
 def test_deterministic_mode_agrees_with_the_atomic_mode():
     """Same numbers up to fp32 re-association (it is the same arithmetic in another summation order), also with a workspace too
-    small for the planned split counts (the launches then run with fewer splits)."""
+    small for the planned split counts (the launches then run with fewer splits).  The sharp check is the FIRST step: every
+    gradient of both networks within 1e-5 relative (observed 2e-8 ... 1e-7).  After an Adam update the runs separate like any two
+    runs of the atomic mode do -- the update moves noise-level entries by +-lr on the sign of a rounding error -- so the second
+    step is only bounded loosely (observed on MI355X: 2e-8 ... 7e-3 depending on the build's rounding, the runs being
+    reproducible bit for bit)."""
     cfg = (2, 8, 128, 2, 1, "bf16")
-    ref, sr = run_steps(cfg, 2)
+
+    def grads_per_step(**okw):
+        ops, eng, xc, xf = make(*cfg, **okw)
+        out = []
+        for step in range(2):
+            ran_g = eng.train_step(xc, xf, torch.from_numpy(synthetic.alpha(cfg[0], step)).cuda())
+            eng.C.P.sync(); eng.G.P.sync()
+            out.append((eng.read_scalars(ran_g), eng.C.P.g.clone(), eng.G.P.g.clone()))
+        ops.close()
+        return out
+    ref = grads_per_step()
     for mb in (512, 2):
-        det, sd = run_steps(cfg, 2, deterministic=True, det_workspace_mb=mb)
-        for r, d in zip(ref, det):
-            for k in r:
-                assert abs(r[k] - d[k]) <= 2e-4 * max(abs(r[k]), 1e-2), (mb, k, r[k], d[k])
-        for x, y in zip(sr[2:], sd[2:]):        # last gradients of C and G
-            assert float((x - y).norm()) <= 2e-3 * float(x.norm()) + 1e-12, mb
+        det = grads_per_step(deterministic=True, det_workspace_mb=mb)
+        for step, (r, d) in enumerate(zip(ref, det)):
+            for k in r[0]:
+                assert abs(r[0][k] - d[0][k]) <= 2e-4 * max(abs(r[0][k]), 1e-2), (mb, step, k, r[0][k], d[0][k])
+            for x, y in zip(r[1:], d[1:]):        # gradients of C and G
+                tol = 1e-5 if step == 0 else 3e-2
+                assert float((x - y).norm()) <= tol * float(x.norm()) + 1e-12, (mb, step, float((x - y).norm() / x.norm()))
 
 
 def test_hip_graph_replay_equals_eager_exactly_when_deterministic():
