@@ -21,7 +21,8 @@ class Epilogue(C.Structure):
                 ("r2", C.c_void_p), ("ldr2", C.c_int64), ("s2", C.c_float),
                 ("mask", C.c_void_p), ("ldmask", C.c_int64), ("mask_slope", C.c_float),
                 ("accumulate", C.c_int), ("mask_bits", C.c_void_p), ("out_bits", C.c_void_p),
-                ("mask_c0", C.c_int), ("mask_last", C.c_int), ("out_q", C.c_void_p), ("out_qs", C.c_void_p), ("ldqs", C.c_int64)]
+                ("mask_c0", C.c_int), ("mask_last", C.c_int), ("out_q", C.c_void_p), ("out_qs", C.c_void_p), ("ldqs", C.c_int64),
+                ("out_u", C.c_void_p), ("out_ue", C.c_void_p)]
 
 
 class ConvGeom(C.Structure):
@@ -74,6 +75,7 @@ _PROTOS = {
     "dg_conv3x3_dgrad": [C.POINTER(ConvGeom), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_wgrad": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp],
     "dg_conv3x3_wgrad_dense": [_vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "dg_conv3x3_wgrad_f8": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp, _vp],
     "dg_gather_gemm": [C.POINTER(GGDesc), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_plan": [C.POINTER(ConvGeom), _i, C.POINTER(GGDesc)],
     "dg_last_conv_kernels": [],
@@ -112,6 +114,7 @@ _PROTOS = {
     "dg_div_vort_sums": [_i, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp],
     "dg_gather_samples": [_i, _vp, _i64, _i, _vp, _i, _vp, _i, _vp],
     "dg_quant_mxfp8": [_i, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i64, _vp],
+    "dg_block_exp_max": [_vp, _i64, _i64, _i, _i, _vp, _vp, _vp],
     "dg_conv3x3_fwd_f8": [C.POINTER(ConvGeom), C.POINTER(Epilogue), C.POINTER(F8Operands), _vp, _vp],
     "dg_conv3x3_dgrad_f8": [C.POINTER(ConvGeom), C.POINTER(Epilogue), C.POINTER(F8Operands), _vp, _vp],
     "dg_moments": [_vp, _i64, _vp, _vp],

@@ -42,6 +42,7 @@ struct GGArgs {
   const float* bias; const void* r1; const void* r2; const void* mask;
   const void* mask_bits; void* out_bits;     // 1-bit LeakyReLU masks (u16 per lane: 4 fragments x 4 channels), see dg_epilogue
   void* out_q; void* out_qs;                 // MXFP8 copy of the stored output (dg_epilogue.out_q / out_qs)
+  void* out_u; const unsigned char* out_ue;  // uniform-scale E4M3 copy for the fp8 weight gradient (dg_epilogue.out_u / out_ue)
   int ldqs, qs_shift;                        // scale bytes per pixel of out_qs; log2(Nout / 16) when that stride is not Nout / 32
   long long ldx, ldw, ldy, ldr1, ldr2, ldmask;
   int M, Hg, Wg, Hs, Ws;
@@ -97,7 +98,7 @@ template <> struct EpiV<float> {
     return t;
   }
 };
-struct EpiRes { __amdgpu_buffer_rsrc_t rY, r1, r2, rm, rbi, rbo, rq, rqs; int ldy, ld1, ld2, ldm; };
+struct EpiRes { __amdgpu_buffer_rsrc_t rY, r1, r2, rm, rbi, rbo, rq, rqs, ru; int ldy, ld1, ld2, ldm; };
 template <typename T> struct EpiIO;
 template <> struct EpiIO<bf16_t> {
   typedef u32x2_t V;
@@ -157,7 +158,8 @@ __device__ __forceinline__ unsigned epi64_bits(const GGArgs& a, const EpiRes& R,
 template <typename T, bool LEAN, int F = -1>
 __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, const f32x4_t& f0, const f32x4_t& f1, const f32x4_t& f2,
                                             const f32x4_t& f3, const float (&bias)[16], unsigned offy, unsigned off1, unsigned off2,
-                                            unsigned offm, unsigned boff, unsigned mb, bool mask_on, unsigned* ob_ret = nullptr) {
+                                            unsigned offm, unsigned boff, unsigned mb, bool mask_on, unsigned* ob_ret = nullptr,
+                                            float inv_u = 0.f) {
   typedef EpiV<T> IO;
   constexpr int NU = IO::NU, CPU = IO::CPU;
   u32x4_t v1[NU], v2[NU], vm[NU], va[NU];
@@ -172,6 +174,7 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
   const bool f_ml = F < 0 ? !LEAN && mask_on && a.mask_last != 0 : (F & 128) != 0;  // mask after it
   const bool f_ac = F < 0 ? !LEAN && a.accumulate != 0 : (F & 64) != 0;
   const bool f_q = F < 0 ? a.out_q != nullptr : (F & 256) != 0;                      // MXFP8 copy of the stored values
+  const bool f_u = F < 0 ? a.out_u != nullptr : (F & 2048) != 0;                     // + the uniform-scale copy (inv_u = 2^(127 - exponent))
   u32x4_t pk[NU];
   // LEAN runs inside a tile loop whose memory operations must be unconditional (see gg_im2col_kernel): absent bit-mask
   // operands become out-of-range offsets (the load returns 0, the store is dropped)
@@ -264,6 +267,10 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
         offqs = (w16 >> a.qs_shift) * (unsigned)a.ldqs + ((w16 & ((1u << a.qs_shift) - 1u)) >> 1);
       }
       __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, R.rqs, (low_half && boff != DG_OOB_OFF) ? offqs : DG_OOB_OFF, 0, 0);
+      if (f_u) {     // the same rounded values on the tensor-wide exponent of their 32-channel block (a non-finite block is poisoned too)
+        const u32x4_t uv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, inv_u), ab));
+        __builtin_amdgcn_raw_buffer_store_b128(uv, R.ru, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
+      }
     }
   }
 }
@@ -309,6 +316,8 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
     R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
     R.rbi = rsrc(a.mask_bits ? a.mask_bits : a.y, ldb, 2); R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
     R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.ldqs, 1);
+    R.ru = rsrc(a.out_u ? a.out_u : a.y, a.ldy, 1);
+    const float inv_u = (a.out_u && cok) ? mx_inv_scale((int)a.out_ue[cb16 >> 5]) : 0.f;
     R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
     int relv[FP];
     bool okv[FP];
@@ -327,7 +336,7 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
       epi64_pixel<T, LEAN>(a, R, acc[0][i], acc[1][i], acc[2][i], acc[3][i], bias,
                            ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
                            ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
-                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i], a.mask && cb16 >= a.mask_c0);
+                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i], a.mask && cb16 >= a.mask_c0, nullptr, inv_u);
     }
     return;
   }
@@ -493,10 +502,13 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
     R.r1 = rsrc(a.r1 ? a.r1 : a.y, a.ldr1, ES); R.r2 = rsrc(a.r2 ? a.r2 : a.y, a.ldr2, ES); R.rm = rsrc(a.mask ? a.mask : a.y, a.ldmask, ES);
     R.rbi = R.rY; R.rbo = rsrc(a.out_bits ? a.out_bits : a.y, ldb, 2);
     R.rq = rsrc(a.out_q ? a.out_q : a.y, a.ldy, 1); R.rqs = rsrc(a.out_qs ? a.out_qs : a.y, a.ldqs, 1);
+    R.ru = rsrc(a.out_u ? a.out_u : a.y, a.ldy, 1);
     R.ldy = (int)a.ldy; R.ld1 = (int)a.ldr1; R.ld2 = (int)a.ldr2; R.ldm = (int)a.ldmask;
     // permuted wave tile (perm64): the lane's four channel fragments are the 16 consecutive channels from cb16
     const int cb16 = c0 + (wc + h) * 64 + 16 * g;
     const bool cok = cb16 < a.Nout && xok;
+    float inv_u = 0.f;
+    if ((F < 0 || (F & 2048)) && a.out_u && cb16 < a.Nout) inv_u = mx_inv_scale((int)a.out_ue[cb16 >> 5]);
     float bias[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -516,14 +528,14 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       epi64_pixel<T, (F >= 0), FE>(a, R, acc[4 * h][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i], bias,
                             ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
                             ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
-                            ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[h][i], a.mask && cb16 >= a.mask_c0);
+                            ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[h][i], a.mask && cb16 >= a.mask_c0, nullptr, inv_u);
     }
   }
   };
   // the flag combinations the train step launches most get straight-line instances; everything else the general one.
   // Decoded per 64-channel half: the activation mask may start at channel mask_c0 (a multiple of 64 here, else general path)
   const int key0 = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.r1 ? 8 : 0) | (a.r2 ? 16 : 0) | (a.accumulate ? 64 : 0) |
-                   (a.out_q ? 256 : 0);
+                   (a.out_q ? 256 : 0) | (a.out_u ? 2048 : 0);
   auto dispatch = [&](auto htag) {
     constexpr int h = decltype(htag)::value;
     int key = key0;
@@ -544,6 +556,8 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       case 280: run(std::integral_constant<int, 280>{}, htag); break;  // fp8 mode: two residuals + MXFP8 copy (RRDB output)
       case 258: run(std::integral_constant<int, 258>{}, htag); break;  // fp8 mode: 1-bit mask + MXFP8 copy (critic data gradients, tangent forward)
       case 261: run(std::integral_constant<int, 261>{}, htag); break;  // fp8 mode: LeakyReLU + out_bits + MXFP8 copy (critic forward)
+      case 2306: run(std::integral_constant<int, 2306>{}, htag); break; // ... + the uniform-scale copy for the fp8 weight gradient (258 + 2048)
+      case 2309: run(std::integral_constant<int, 2309>{}, htag); break; // (261 + 2048)
       default: run(std::integral_constant<int, -1>{}, htag); break;
     }
   };

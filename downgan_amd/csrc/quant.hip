@@ -78,3 +78,41 @@ extern "C" int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int6
   else return DG_ERR_BAD_DTYPE;
   return dg_check_launch();
 }
+
+// ---- per-block maximum of the MXFP8 scale bytes of a tensor (rows x nblocks bytes): the exponents of its uniform-scale copy.
+// Threads walk dwords of the byte matrix (nblocks is a multiple of 4: channel counts are multiples of 128) with a running
+// byte-wise maximum, then one atomicMax per block into the caller's 64-dword scratch (zero at rest: the finish kernel clears it).
+__global__ void __launch_bounds__(256) block_exp_max_kernel(const unsigned* __restrict__ sc, long long rows, long long ld4, int nb4,
+                                                            unsigned* __restrict__ tmp) {
+  const int col = threadIdx.x % nb4, sub = threadIdx.x / nb4, nsub = 256 / nb4;
+  if (sub >= nsub) return;
+  unsigned m = 0;
+  for (long long r = (long long)blockIdx.x * nsub + sub; r < rows; r += (long long)gridDim.x * nsub) {
+    const unsigned v = sc[r * ld4 + col];
+    unsigned r4 = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const unsigned x = (v >> (8 * b)) & 0xffu, y = (m >> (8 * b)) & 0xffu; r4 |= (x > y ? x : y) << (8 * b); }
+    m = r4;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) atomicMax(tmp + col * 4 + b, (m >> (8 * b)) & 0xffu);
+}
+__global__ void block_exp_finish_kernel(unsigned* __restrict__ tmp, int nblocks, int margin, unsigned char* __restrict__ out) {
+  const int b = threadIdx.x;
+  if (b < nblocks) { const unsigned v = tmp[b] + (unsigned)margin; out[b] = (unsigned char)(v > 254u ? 254u : v); tmp[b] = 0u; }
+}
+
+extern "C" int dg_block_exp_max(const void* scales, int64_t rows, int64_t ld, int nblocks, int margin, void* out, void* scratch, void* stream) {
+  if (!scales || !out || !scratch) return DG_ERR_BAD_ARG;
+  if (rows <= 0 || nblocks <= 0 || nblocks > 64 || nblocks % 4 || ld < nblocks || ld % 4 || margin < 0 || margin > 8) return DG_ERR_BAD_SHAPE;
+  if (reinterpret_cast<uintptr_t>(scales) % 4 || reinterpret_cast<uintptr_t>(scratch) % 4) return DG_ERR_BAD_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nb4 = nblocks / 4, nsub = 256 / nb4;
+  long long nwg = (rows + (long long)nsub * 64 - 1) / ((long long)nsub * 64);
+  if (nwg > 2048) nwg = 2048;
+  if (nwg < 1) nwg = 1;
+  hipLaunchKernelGGL(block_exp_max_kernel, dim3((unsigned)nwg), dim3(256), 0, st, (const unsigned*)scales, (long long)rows, (long long)(ld / 4), nb4,
+                     (unsigned*)scratch);
+  hipLaunchKernelGGL(block_exp_finish_kernel, dim3(1), dim3(64), 0, st, (unsigned*)scratch, nblocks, margin, (unsigned char*)out);
+  return dg_check_launch();
+}

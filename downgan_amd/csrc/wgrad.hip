@@ -29,6 +29,7 @@ struct WGArgs {
   // deterministic mode (dg_internal.h DetPlan): split `by` accumulates into copy `by` of the target region inside the workspace
   // instead of the gradient itself: dw / dwk[] / dbk[] keep their offsets from det_base, db sits at det_db_off of the copy
   float* det_ws; const float* det_base; long long det_stride, det_db_off;
+  const unsigned char* ex; const unsigned char* eu;   // fp8 kernel: E8M0 exponent byte per 32-channel block of x / of the adjoint
 };
 #define WG_DET_PTR(a, p, by) ((a).det_ws ? (a).det_ws + (long long)(by) * (a).det_stride + ((p) - (a).det_base) : (p))
 #define WG_DET_DB(a, by) ((a).det_ws ? (a).det_ws + (long long)(by) * (a).det_stride + (a).det_db_off : (a).db)
@@ -914,6 +915,213 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
   constexpr int lds = 3 * (32 * 256 + (S2 ? 68 : 36) * 256);
   if (lds > 65536) DG_SET_MAX_LDS_ONCE((&wg3w_kernel<S2>), lds);
   hipLaunchKernelGGL((wg3w_kernel<S2>), dim3(ntiles, splits), dim3(256), lds, st, a);
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return wg_det_end(a, plan, lo, span, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fp8 weight gradient (BASELINE configs[4]): the wide row-of-taps kernel on v_mfma_scale_f32_32x32x64_f8f6f4.
+// The contraction runs over PIXELS, so the MXFP8 forms of the conv path (one scale per pixel and 32 channels) cannot feed it:
+// a K block of 32 pixels would need one scale.  The operands here are E4M3 tensors with a scale that does not vary along
+// pixels -- one E8M0 exponent per 32-channel block of the whole tensor (`ex` / `eu`; x = q * 2^(e - 127)) -- so every window
+// of 64 pixels is a valid K step for all three taps of a kernel row, and the two per-block scales of a fragment pair go into
+// the MFMA's scale operands (each lane supplies its row's / column's exponent; both K blocks get the same one).
+// Register maps measured with tools/fp8_probe3.hip: A / B lane l = row / column l % 32, 32 bytes; byte j of lane half
+// l / 32 is the same k for A and B (so any assignment of the 64 pixels to (half, byte) works as long as both operands use
+// it); D as the bf16 32x32 shapes.  ds_read_b64_tr_b8: in a group of 16 lanes, lane 8p + i receives byte i of the eight
+// 8-byte rows supplied by lanes 2j + p (j = 0..7): source lanes 2j / 2j + 1 point at channels c .. c+7 / c+8 .. c+15 of
+// pixel j, and the 16 lanes of the group end up with 16 consecutive channels x 8 consecutive pixels.
+// Tile and schedule as wg3w_kernel (128 adjoint x 128 input channels x 3 taps, DMA-staged three-buffer ring, one barrier per
+// step) with 64-pixel steps: tile rows are 128 B, a DMA piece = 8 rows, LDS 3 x 17 KB.  The 32-byte chunk index of a row is
+// XOR-ed with (row >> 1) & 3 on the source side of the DMA: the eight rows of a transposing read then cover all 64 banks.
+// Stride 1, channel counts that are multiples of 128, rows of a multiple of 64 pixels.
+typedef __attribute__((ext_vector_type(8))) int i32x8w_t;
+typedef __attribute__((ext_vector_type(2))) int i32x2w_t;
+typedef __attribute__((address_space(3))) i32x2w_t* lds_i32x2_ptr;
+
+__global__ __launch_bounds__(256, 2) void wg3w_f8_kernel(const WGArgs a) {
+  constexpr int BCO = 128, BCI = 128, KP = 64, ROWB = 128;
+  constexpr int XROWS = KP + 2, UPIECES = KP / 8, XPIECES = KP / 8 + 1;       // 8 adjoint pieces, 9 input pieces (rows 66..71 never read)
+  constexpr int SU_B = KP * ROWB, SX_B = XPIECES * 8 * ROWB, BUFB = SU_B + SX_B;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg8_dsm[];          // 3 * BUFB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned lin = gridDim.x <= 72 ? xcd_remap(lin0, gridDim.x * gridDim.y) : lin0;
+  const int bx = (int)(lin % gridDim.x), by = (int)(lin / gridDim.x);
+  const int ci_t = bx % a.nci_t, trow = (bx / a.nci_t) % 3, co_t = bx / (a.nci_t * 3);
+  const int co0 = co_t * BCO, ci0 = ci_t * BCI;
+  const int dr = trow - 1;
+  const int pbeg = by * a.ppb;
+  const int pend = min(a.Mpix, pbeg + a.ppb);
+  const int nsteps = (pend - pbeg + KP - 1) / KP;
+  if (nsteps <= 0) return;
+  const char* X = reinterpret_cast<const char*>(a.x);
+  const char* U = reinterpret_cast<const char*>(a.u);
+
+  // DMA lane constants: a piece = 8 rows x 128 B; lane -> (row 8p + lane / 8, physical 16-byte chunk lane % 8), which holds the
+  // logical chunk with the 32-byte index XOR-ed by (row >> 1) & 3 (8p does not reach those bits).  ONE lane offset per tensor
+  // (row-in-piece and chunk); the piece's first row goes into the instruction's scalar offset, the channel tile into the base --
+  // per-piece lane offsets (8 registers) made the 192 + 32 accumulator / fragment registers spill inside the loop
+  const int drow = lane >> 3, pchunk = lane & 7;
+  const int lchunk = ((((pchunk >> 1) ^ ((drow >> 1) & 3)) << 1) | (pchunk & 1)) * 16;          // byte offset inside the 128-byte row
+  const unsigned ulane = (unsigned)(drow * (int)a.ldu + lchunk), xlane = (unsigned)(drow * (int)a.ldx + lchunk);
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)wg8_dsm));
+  typedef int i32x4w_t __attribute__((ext_vector_type(4)));
+  auto dma = [&](unsigned m0v, unsigned voff, const i32x4w_t& rs, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  };
+  auto make_rs = [&](const char* base) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4w_t rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
+    rs[2] = (int)WG_OOB_OFF;
+    rs[3] = 0x00020000;
+    return rs;
+  };
+  int s_wo = pbeg % a.Wo, s_ho, s_n;
+  { const int t = pbeg / a.Wo; s_ho = t % a.Ho; s_n = t / a.Ho; }
+  // tile t (64 output pixels of one row + the 66 input pixels under them) -> buffer buf.  A lane whose input pixel lies outside
+  // the image gets the out-of-range offset (the range check looks at the lane offset only: the load returns zeros).
+  auto issue = [&](int buf, int t) {
+    const long long ub = ((long long)(s_n * a.Ho + s_ho) * a.Wo + s_wo) * a.ldu + co0;
+    const int hi = s_ho + dr;
+    const bool row_ok = (unsigned)hi < (unsigned)a.H;
+    const int wi0 = s_wo - 1;                                   // input column of tile row 0
+    const long long xb = ((long long)(s_n * a.H + (row_ok ? hi : 0)) * a.W + wi0) * a.ldx + ci0;
+    const i32x4w_t rsU = make_rs(U + ub), rsX = make_rs(X + xb);
+    const unsigned m0b = lds0 + (unsigned)buf * BUFB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma(m0b + (unsigned)(wave + 4 * j) * 1024u, ulane, rsU, (unsigned)((wave + 4 * j) * 8 * (int)a.ldu));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row0 = 8 * (wave + 4 * j);
+      const unsigned vo = (row_ok && (unsigned)(wi0 + row0 + drow) < (unsigned)a.W) ? xlane : WG_OOB_OFF;
+      dma(m0b + SU_B + (unsigned)(wave + 4 * j) * 1024u, vo, rsX, (unsigned)(row0 * (int)a.ldx));
+    }
+    if ((t & 3) == wave) {                                      // rows 64 .. 71 (64, 65 are read): one wave per step, in turn
+      const unsigned vo = (row_ok && drow < XROWS - KP && (unsigned)(wi0 + KP + drow) < (unsigned)a.W) ? xlane : WG_OOB_OFF;
+      dma(m0b + SU_B + (unsigned)(XPIECES - 1) * 1024u, vo, rsX, (unsigned)(KP * (int)a.ldx));
+    }
+    s_wo += KP;
+    if (s_wo >= a.Wo) { s_wo = 0; if (++s_ho == a.Ho) { s_ho = 0; ++s_n; } }
+  };
+
+  f32x16_t acc[3][4];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[s][f][e] = 0.f;
+
+  // fragment read offsets inside a buffer.  Lane l: half h = l / 32 (pixels 32h ..), channel group G = (l / 16) & 1, source role
+  // sl = l % 16: pixel row sl / 2 of the eight, channels + 8 * (sl & 1).  Read q of a fragment covers pixels 32h + 8q .. + 7.
+  const int h = lane >> 5, G = (lane >> 4) & 1, sl = lane & 15, prow = sl >> 1, low = 16 * G + 8 * (sl & 1), r32 = lane & 31;
+  const int bu = (32 * h + prow) * ROWB + (((prow >> 1) & 3) << 5) + low;            // adjoint fragment f, read q: (bu ^ (f << 5)) + q * 8 * ROWB
+  int bxs[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) bxs[s] = SU_B + (32 * h + prow + s) * ROWB + ((wave ^ (((prow + s) >> 1) & 3)) << 5) + low;
+  // exponent bytes: adjoint fragment f = 32-channel block co0 / 32 + f, this wave's input columns = block ci0 / 32 + wave
+  const unsigned eu4 = *reinterpret_cast<const unsigned*>(a.eu + (co0 >> 5));
+  const int sxb = (int)a.ex[(ci0 >> 5) + wave];
+
+  issue(0, 0);
+  if (nsteps > 1) issue(1, 1);
+  auto wait_older = [&](bool newest_in_flight) {
+    if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // a tile = 4 or 5 pieces per wave: everything older than the newest has landed
+  };
+  wait_older(nsteps > 1);
+  __syncthreads();
+  int cur = 0;
+  for (int ks = 0; ks < nsteps; ++ks) {
+    const bool ahead = ks + 2 < nsteps;
+    int nb = cur + 2; if (nb >= 3) nb -= 3;
+    if (ahead) issue(nb, ks + 2);            // buffer (ks + 2) % 3 was last read in step ks - 1, behind that step's barrier
+    const unsigned char* sb = wg8_dsm + cur * BUFB;
+    auto read_frag = [&](int off) {
+      i32x8w_t v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const i32x2w_t t = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2_ptr)(sb + off + q * 8 * ROWB));
+        v[2 * q] = t[0]; v[2 * q + 1] = t[1];
+      }
+      return v;
+    };
+    i32x8w_t fb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) fb[s] = read_frag(bxs[s]);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      // 192 accumulator + 24 input-fragment registers leave room for ONE adjoint fragment: its read latency is in the open (the
+      // second workgroup of the CU covers it); a second one in flight spilled 13 registers
+      __builtin_amdgcn_sched_barrier(0);
+      const i32x8w_t fa = read_frag(bu ^ (f << 5));
+      __builtin_amdgcn_sched_barrier(0);
+      const int sua = (int)((eu4 >> (8 * f)) & 0xffu);
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        acc[s][f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[s], acc[s][f], 0, 0, 0, sua, 0, sxb);
+      // (the fence keeps the next fragment's reads behind these MFMAs: hoisted, all four adjoint fragments are live at once)
+      asm volatile("" : "+v"(acc[0][f]), "+v"(acc[1][f]), "+v"(acc[2][f]) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wait_older(ahead);
+    __syncthreads();
+    if (++cur == 3) cur = 0;
+  }
+
+  // epilogue (wg3w_kernel's): one lane-constant 32-bit offset, the rest of an element's address is workgroup-uniform
+  float* const dw_out = WG_DET_PTR(a, a.dw, by);
+  const long long ldw = 9ll * a.Cin;
+  const int ci = ci0 + wave * 32 + r32;
+  const unsigned lane_off = (unsigned)((((long long)co0 + 4 * h) * ldw + ci) * 4);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int tap = trow * 3 + s;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int cor = 32 * f + (reg & 3) + 8 * (reg >> 2);             // + co0 + 4h
+        char* const base = reinterpret_cast<char*>(dw_out) + ((long long)cor * ldw + (long long)tap * a.Cin) * 4;
+        atomicAdd(reinterpret_cast<float*>(base + lane_off), acc[s][f][reg]);
+      }
+  }
+}
+
+// dw[co][tap][ci] (fp32, accumulated into) += sum_p dy[p, co] * x[src(p, tap), ci] for E4M3 operands with per-32-channel-block
+// exponents: x = xq * 2^(ex[ci / 32] - 127), dy = dyq * 2^(ey[co / 32] - 127) (`ldx` / `ldy` of g = pixel strides in bytes).
+extern "C" int dg_conv3x3_wgrad_f8(const dg_conv_geom* g, const void* xq, const void* ex, const void* dyq, const void* ey, float* dw,
+                                   void* stream) {
+  if (!g || !xq || !ex || !dyq || !ey || !dw) return DG_ERR_BAD_ARG;
+  if (g->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;               // (the dtype of the tensors the fp8 forms stand for)
+  if (g->N <= 0 || g->H <= 0 || g->W <= 0 || g->stride != 1 || g->pixel_shuffle) return DG_ERR_BAD_SHAPE;
+  if (g->Cin <= 0 || g->Cout <= 0 || g->Cin % 128 || g->Cout % 128 || g->W % 64) return DG_ERR_BAD_SHAPE;
+  if (g->ldx < g->Cin || g->ldy < g->Cout || g->ldx % 16 || g->ldy % 16) return DG_ERR_BAD_SHAPE;
+  WGArgs a{};
+  a.x = xq; a.u = dyq; a.dw = dw; a.ldx = g->ldx; a.ldu = g->ldy;
+  a.ex = (const unsigned char*)ex; a.eu = (const unsigned char*)ey;
+  a.H = g->H; a.W = g->W; a.stride = 1; a.Ho = g->H; a.Wo = g->W;
+  a.Cin = g->Cin; a.Cout = g->Cout; a.u_ps = 0; a.cps_chunks = 1;
+  const long long mp = (long long)g->N * a.Ho * a.Wo;
+  if (mp >= (1ll << 31) || (long long)(a.W + 8) * a.ldx >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
+  a.Mpix = (int)mp;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  constexpr int BCO = 128, BCI = 128;
+  const int nco_t = a.Cout / BCO;
+  a.nci_t = a.Cin / BCI;
+  const int ntiles = 3 * nco_t * a.nci_t;
+  const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
+  const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // the atomics-traffic budget of the bf16 launchers
+  int splits = wg_pick_splits(ntiles, 1536, cap, a.Mpix, &a.ppb);                   // 3 rounds of 512 slots (2 per CU)
+  DetPlan plan; float* lo = nullptr; long long span = 0;
+  const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
+  if (granted < 0) return DG_ERR_LAUNCH;
+  if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb);
+  constexpr int lds = 3 * (64 * 128 + 72 * 128);
+  hipLaunchKernelGGL(wg3w_f8_kernel, dim3(ntiles, splits), dim3(256), lds, st, a);
   if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
   return wg_det_end(a, plan, lo, span, st);
 }

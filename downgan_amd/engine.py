@@ -275,6 +275,20 @@ class NativeCritic:
                 if o.f8_eligible(cv, "fwd"):
                     self.wq_f[l] = (o.zeros(cv.Cout * 9, cv.Cin, dtype=torch.uint8), o.zeros(cv.Cout * 9, cv.Cin // 32, dtype=torch.uint8))
             P.after_refresh.append(self._requantise_weights)
+        # fp8 WEIGHT GRADIENTS (dg_conv3x3_wgrad_f8): the contraction runs over pixels, so the operands are second fp8 copies whose
+        # scale does not vary along pixels -- one exponent per 32-channel block of the whole tensor, taken from the MXFP8 scale bytes
+        # of the PREVIOUS pass over the same buffer (delayed scaling: ops.block_exp_max after the pass that consumed the copy).  The
+        # producing epilogue writes the copy (dg_epilogue.out_u) beside the MXFP8 one: activation act[l-1] and adjoint us[l] of every
+        # eligible layer l, and the penalty's tangents.  Until a role's exponents exist (first pass) its layers use the bf16 kernel.
+        ubuf = lambda t: (o.zeros(*t.shape, dtype=torch.uint8), o.zeros(t.shape[-1] // 32, dtype=torch.uint8))
+        self.wg8 = [self.f8 and l > 0 and bool(o.f8_eligible(cv, "wgrad")) and self.actq[l - 1] is not None and self.usq[l] is not None
+                    for l, cv in enumerate(self.convs)]
+        self.actu = [ubuf(self.acts[l]) if l + 1 < 8 and self.wg8[l + 1] else None for l in range(8)]
+        self.usu = [ubuf(self.us[l]) if self.wg8[l] else None for l in range(8)]
+        self.tan_exp = [o.zeros(self.acts[l].shape[-1] // 32, dtype=torch.uint8) if l + 1 < 8 and self.wg8[l + 1] else None for l in range(8)]
+        self._tanu = None
+        self._act_exp_ok = self._us_exp_ok = self._tan_exp_ok = False     # exponents of the role initialised by an earlier pass
+        self._u_act_live = False                                          # this pass's forward wrote valid uniform-scale activations
 
     def _requantise_weights(self):
         o, P = self.ops, self.P
@@ -322,16 +336,21 @@ class NativeCritic:
         return self.unpack(self.P.to_host(self.P.g))
 
     # ---- forward ------------------------------------------------------------------------------------
-    def forward(self, x, fc1_slot=None):
+    def forward(self, x, fc1_slot=None, for_wgrad=False):
         """critic.py:101-106.  x: NHWC [B, fine, fine, c_pad[0]].  Returns out[:, 0] (fp32 view).
-        ``fc1_slot``: keep FC1's input rows of this pass for the iteration's single FC1 weight-gradient sweep."""
+        ``fc1_slot``: keep FC1's input rows of this pass for the iteration's single FC1 weight-gradient sweep.
+        ``for_wgrad`` (fp8 mode): a backward with weight gradients follows -- also write the uniform-scale fp8 activations."""
         o, P = self.ops, self.P
         if self.fc1_fused:
             s = 3 if fc1_slot is None else fc1_slot
             self.acts[7] = self._y7_all[s * self.B:(s + 1) * self.B]
         cur = x
+        want_u = self.f8 and for_wgrad and self._act_exp_ok
+        self._u_act_live = want_u
         for l, cv in enumerate(self.convs):
             f8kw = dict(xq=self.actq[l - 1] if l else None, wq=self.wq_f[l], out_q=self.actq[l]) if self.f8 else {}
+            if want_u and self.actu[l] is not None:
+                f8kw["out_u"] = self.actu[l]
             o.conv_fwd(cv, cur, P.w(f"features.{2 * l}.weight"), self.acts[l],
                        bias=P.master("features.0.bias") if l == 0 else None, act=C_SLOPE,
                        out_bits=self.act_bits[l] if self.act_bits else None, **f8kw)
@@ -346,7 +365,7 @@ class NativeCritic:
         return self.out
 
     # ---- adjoint chain (backward of a forward just run on x) ---------------------------------------
-    def backward(self, x, dout_value, wgrad=True, dx=None, fc1_slot=None):
+    def backward(self, x, dout_value, wgrad=True, dx=None, fc1_slot=None, update_exp=True):
         """d(out_b)/d(.) * dout_value for every sample.  wgrad: accumulate parameter gradients
         (autograd backward of wasserstein.py:52); dx: if given, receives the input gradient
         (wasserstein.py:100-106 / :80).  ``fc1_slot``: FC1's adjoint rows go to that slot and its weight gradient is left
@@ -368,20 +387,44 @@ class NativeCritic:
                     mask=y7, mask_slope=C_SLOPE, o_real=FC_HID, net="C")
         if self.usq[7] is not None:       # the only adjoint that does not come out of a conv epilogue
             o.quant_mxfp8(self.us[7], *self.usq[7])
+        us_u = self.f8 and self._us_exp_ok          # this pass's adjoints get (valid) uniform-scale copies
         for l in range(7, -1, -1):
             cv = self.convs[l]
             name = f"features.{2 * l}.weight"
             xin = self.acts[l - 1] if l > 0 else x
             if wgrad:   # features.0 also carries the only conv bias of the critic (critic.py:21-23)
-                o.conv_wgrad(cv, xin, self.us[l], P.grad(name).reshape(-1), db=P.grad("features.0.bias") if l == 0 else None)
+                if self.f8 and self.wg8[l] and us_u and self._u_act_live:
+                    o.conv_wgrad_f8(cv, self.actu[l - 1][0], self.actu[l - 1][1], self.usu[l][0], self.usu[l][1], P.grad(name).reshape(-1))
+                else:
+                    o.conv_wgrad(cv, xin, self.us[l], P.grad(name).reshape(-1), db=P.grad("features.0.bias") if l == 0 else None)
             if l > 0:
                 f8kw = dict(xq=self.usq[l], wq=self.wq_d[l], out_q=self.usq[l - 1]) if self.f8 else {}
+                if us_u and self.usu[l - 1] is not None:
+                    f8kw["out_u"] = self.usu[l - 1]
                 if self.act_bits:
                     o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask_bits=self.act_bits[l - 1], mask_slope=C_SLOPE, **f8kw)
                 else:
                     o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask=self.acts[l - 1], mask_slope=C_SLOPE, **f8kw)
             elif dx is not None:
                 o.conv_dgrad(cv, self.us[0], P.wd(name), dx)
+        self._us_live = us_u
+        if self.f8 and update_exp:            # (the penalty pass updates after its tangent weight gradients have read the adjoint copies)
+            self._update_exponents(acts=wgrad)
+
+    def _update_exponents(self, acts=True):
+        """After a pass's weight gradients have consumed the uniform-scale copies: the exponents the NEXT pass writes them with =
+        the largest MXFP8 block exponent this pass's tensors reached (+1: values may grow from pass to pass; saturation at +-448
+        beyond that, like the MX rule itself)."""
+        o = self.ops
+        for l in range(8):
+            if acts and self.actu[l] is not None:
+                o.block_exp_max(self.actq[l][1], self.actu[l][1])
+            if self.usu[l] is not None:
+                o.block_exp_max(self.usq[l][1], self.usu[l][1])
+        if acts and any(u is not None for u in self.actu):
+            self._act_exp_ok = True
+        if any(u is not None for u in self.usu):
+            self._us_exp_ok = True
 
     # ---- gradient penalty: forward, adjoint, norm, tangent forward + weight gradients -------------
     def fc1_flush(self, accumulate=False):
@@ -398,8 +441,10 @@ class NativeCritic:
         the tangent is v0 = dGP/dg pushed forward through the same masked linear maps."""
         o, P = self.ops, self.P
         self.forward(xhat)
-        self.backward(xhat, 1.0, wgrad=False, dx=g_buf, fc1_slot=fc1_slot)
+        self.backward(xhat, 1.0, wgrad=False, dx=g_buf, fc1_slot=fc1_slot, update_exp=False)
         self.gp_tangent(g_buf, v_buf, ss, coef, gp_scalar, hp, b_global, 0, fc1_slot)
+        if self.f8:
+            self._update_exponents(acts=False)
 
     def gp_tangent(self, g_buf, v_buf, ss, coef, gp_scalar, hp: HyperParams, b_global, r0, fc1_slot):
         """Second half of the penalty (after g = dC/dx-hat is in ``g_buf``): norm, v0 = dGP/dg, tangent forward and the
@@ -424,10 +469,17 @@ class NativeCritic:
             o.fill_col(self._ones, 0, 1.0)
             if self.f8:
                 self._tanq = [(o.zeros(big, dtype=torch.uint8), o.zeros(big // 32, dtype=torch.uint8)) for _ in range(2)]
-        t, tq = v_buf, None
+                if any(e is not None for e in self.tan_exp):
+                    self._tanu = [o.zeros(big, dtype=torch.uint8) for _ in range(2)]
+        t, tq, tu = v_buf, None, None          # the tangent t_{l-1}, its MXFP8 form, its uniform-scale form (bytes, exponents)
         for l, cv in enumerate(self.convs):
             name = f"features.{2 * l}.weight"
-            o.conv_wgrad(cv, t, us[l], P.grad(name).reshape(-1))
+            if self.f8 and self.wg8[l] and tu is not None and getattr(self, "_us_live", False) and r0 == 0:
+                o.conv_wgrad_f8(cv, tu[0], tu[1], self.usu[l][0], self.usu[l][1], P.grad(name).reshape(-1))
+            else:
+                o.conv_wgrad(cv, t, us[l], P.grad(name).reshape(-1))
+            if self.f8 and l > 0 and self.tan_exp[l - 1] is not None and tq is not None:
+                o.block_exp_max(tq[1], self.tan_exp[l - 1])     # t_{l-1}'s copy has been consumed: exponents for the next tangent pass
             tn = self._tan[l & 1][:self.acts[l].numel()].view(self.acts[l].shape)
             if l == 7 and fc1_slot is not None:           # FC1's tangent input rows stay for fc1_flush
                 tn = self._y7_all[fc1_slot * B:(fc1_slot + 1) * B]
@@ -437,11 +489,17 @@ class NativeCritic:
                     n, sh = self.acts[l].numel(), self.acts[l].shape
                     tqn = (self._tanq[l & 1][0][:n].view(sh), self._tanq[l & 1][1][:n // 32].view(*sh[:-1], sh[-1] // 32))
                 f8kw = dict(xq=tq, wq=self.wq_f[l], out_q=tqn)
+            tun = None
+            if self.f8 and self.tan_exp[l] is not None and tqn is not None and self._tan_exp_ok:
+                tun = (self._tanu[l & 1][:self.acts[l].numel()].view(self.acts[l].shape), self.tan_exp[l])
+                f8kw["out_u"] = tun
             if bits:
                 o.conv_fwd(cv, t, P.w(name), tn, mask_bits=bits[l], mask_slope=C_SLOPE, **f8kw)
             else:
                 o.conv_fwd(cv, t, P.w(name), tn, mask=acts[l], mask_slope=C_SLOPE, **f8kw)
-            t, tq = tn, tqn
+            t, tq, tu = tn, tqn, tun
+        if self.f8 and any(e is not None for e in self.tan_exp):
+            self._tan_exp_ok = True
         t7 = t.view(B, self.fc_k)
         if fc1_slot is None:
             o.linear_dw(uh1[:, :FC_HID_P], t7, P.grad("classifier.0.weight"), o_real=FC_HID, net="C")
@@ -944,7 +1002,7 @@ class TrainEngine:
                 xr = self.real_c
         s0, s1, s2 = (0, 1, 2) if C.fc1_fused else (None, None, None)
         C.P.zero_grad(skip="classifier.0.weight" if C.fc1_fused else None)    # :43 (fc1_flush WRITES that gradient)
-        out = C.forward(xr, s0)                                   # :37
+        out = C.forward(xr, s0, for_wgrad=True)                   # :37
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
         C.backward(xr, -1.0 / bg, fc1_slot=s0)                    # d(-mean c_real)
         if real_first:
@@ -952,7 +1010,7 @@ class TrainEngine:
         if real_first or not self.compact2:
             o.gp_interp(fine, fake, alpha, self.xhat, None, self.fake_c)      # :94
         xk = self.fake_c if self.compact2 else fake
-        out = C.forward(xk, s1)                                   # :38
+        out = C.forward(xk, s1, for_wgrad=True)                   # :38
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
         C.backward(xk, 1.0 / bg, fc1_slot=s1)                     # d(+mean c_fake)
         C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, fc1_slot=s2)   # :40,:87-117
@@ -1137,10 +1195,10 @@ class TrainEngineFS(TrainEngine):
         xr, xk = (self.real_c, self.fake_c) if self.compact2 else (self.real_high, self.fake_high)
         s0, s1, s2 = (0, 1, 2) if C.fc1_fused else (None, None, None)
         C.P.zero_grad(skip="classifier.0.weight" if C.fc1_fused else None)    # :49 (fc1_flush WRITES that gradient)
-        out = C.forward(xr, s0)                                   # :43
+        out = C.forward(xr, s0, for_wgrad=True)                   # :43
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_real_mean"))
         C.backward(xr, -1.0 / bg, fc1_slot=s0)
-        out = C.forward(xk, s1)                                   # :44
+        out = C.forward(xk, s1, for_wgrad=True)                   # :44
         o.sum_strided(out, B, out.stride(0), 1.0 / B, self._sc("c_fake_mean"))
         C.backward(xk, 1.0 / bg, fc1_slot=s1)
         C.gp_pass(self.xhat, self.gbuf, self.vbuf, self.ss, self.coef, self._sc("gp_ret"), hp, bg, fc1_slot=s2)

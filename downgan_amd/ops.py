@@ -115,6 +115,7 @@ class HipOps:
         self.prof = None      # optional list of (tag, flops, bytes, start_event, end_event): bench.py's live kernel timing
         self.f8 = bool(f8_critic or f8_generator)
         self.f8_generator = bool(f8_generator)
+        self.f8_wgrad = os.environ.get("DG_NO_F8_WGRAD") is None     # fp8 weight gradients of the eligible critic layers (f8 mode only)
         assert not self.f8 or dtype == "bf16", "the fp8 conv path quantises bf16 tensors"
         self._f8_scratch = {}
         if deterministic is None:
@@ -220,7 +221,7 @@ class HipOps:
         return (N, H, W, Cc // 64, 4)
 
     def _epilogue(self, out, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None, mask_slope=1.0,
-                  accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None):
+                  accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None):
         ep = Epilogue()
         ep.bias = bias.data_ptr() if bias is not None else None
         if bias is not None:
@@ -257,6 +258,11 @@ class HipOps:
             assert tuple(qs.shape) == tuple(out.shape[:-1]) + (Cc // 32,) and qs.stride(-1) == 1
             assert all(qs.stride(i) * out.stride(2) == out.stride(i) * qs.stride(2) for i in range(3)), (qs.stride(), out.stride())
             ep.out_q, ep.out_qs, ep.ldqs = q.data_ptr(), qs.data_ptr(), qs.stride(2)
+        if out_u is not None:       # (u8, exps): the uniform-scale E4M3 copy for the fp8 weight gradient (one exponent per 32-channel block)
+            u, ue = out_u
+            assert out_q is not None and u.dtype == torch.uint8 and u.shape == out.shape and u.stride() == out.stride()
+            assert ue.dtype == torch.uint8 and ue.is_contiguous() and ue.numel() == out.shape[-1] // 32
+            ep.out_u, ep.out_ue = u.data_ptr(), ue.data_ptr()
         return ep
 
     # ------------------------------------------------------------------ conv family
@@ -266,7 +272,12 @@ class HipOps:
         return (cv.N, cv.Ho, cv.Wo, cv.Cout)
 
     def f8_eligible(self, cv: Conv, kind):
-        """Does this layer's forward ("fwd") / data gradient ("dgrad") run on the MXFP8 kernel in f8 mode?"""
+        """Does this layer's forward ("fwd") / data gradient ("dgrad") run on the MXFP8 kernel in f8 mode, its weight gradient
+        ("wgrad") on the fp8 kernel with uniform-scale operands (dg_conv3x3_wgrad_f8: stride 1, channel counts that are multiples
+        of 128, rows of a multiple of 64 pixels)?"""
+        if kind == "wgrad":
+            return (self.f8 and self.f8_wgrad and cv.net == "C" and cv.stride == 1 and not cv.pixel_shuffle and cv.Cin % 128 == 0
+                    and cv.Cout % 128 == 0 and cv.W % 64 == 0)
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
         nets = ("C", "G") if (self.f8_generator and kind == "fwd") else ("C",)
         return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
@@ -327,6 +338,20 @@ class HipOps:
         check(self.lib.dg_quant_mxfp8(sdt, _ptr(src), rows, ld, Cc, _ptr(q), ldq, _ptr(scales), ldqs, self._stream()), "dg_quant_mxfp8")
         return q, scales
 
+    def block_exp_max(self, scales, out, margin=1):
+        """out[b] (uint8 [C / 32]) = min(254, max over pixels of the MXFP8 scale bytes of block b + margin): the exponents the
+        NEXT pass's uniform-scale copy of this tensor is written with (dg_block_exp_max)."""
+        nb = scales.shape[-1]
+        assert scales.dtype == torch.uint8 and out.dtype == torch.uint8 and out.numel() == nb and scales.stride(-1) == 1
+        ld = scales.stride(-2)
+        rows = scales.numel() // nb
+        assert scales.dim() == 2 or all(scales.stride(i) == scales.stride(i + 1) * scales.shape[i + 1] for i in range(scales.dim() - 2)), scales.stride()
+        if self._exp_scratch is None:
+            self._exp_scratch = torch.zeros(64, dtype=torch.int32, device=self.device)
+        check(self.lib.dg_block_exp_max(_ptr(scales), rows, ld, nb, int(margin), _ptr(out), _ptr(self._exp_scratch), self._stream()), "dg_block_exp_max")
+
+    _exp_scratch = None
+
     def _f8_buf(self, key, shape):
         n = 1
         for d in shape:
@@ -360,6 +385,17 @@ class HipOps:
         g = self._geom(cv, pix_layout(x)[0], pix_layout(dy)[0])
         check(self._timed("conv_wgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad(
             C.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), self._stream()), self.conv_bytes(cv), cv.net, self._geom_tag(cv)), "dg_conv3x3_wgrad")
+
+    def conv_wgrad_f8(self, cv: Conv, xq, ex, dyq, ey, dw):
+        """dw (flat fp32, accumulated into) += weight gradient from E4M3 operands with per-32-channel-block exponents (uint8 tensors
+        ``ex`` [Cin / 32], ``ey`` [Cout / 32]; x = xq * 2^(ex - 127)): dg_conv3x3_wgrad_f8.  Raises on shapes the kernel does not
+        take (stride 2, channel counts that are not multiples of 128, rows that are not multiples of 64 pixels)."""
+        assert xq.dtype == torch.uint8 and dyq.dtype == torch.uint8 and ex.dtype == torch.uint8 and ey.dtype == torch.uint8
+        assert dw.dtype == torch.float32 and dw.numel() == cv.Cout * 9 * cv.Cin and ex.numel() == cv.Cin // 32 and ey.numel() == cv.Cout // 32
+        g = self._geom(cv, pix_layout(xq)[0], pix_layout(dyq)[0])
+        check(self._timed("conv_wgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad_f8(
+            C.byref(g), _ptr(xq), _ptr(ex), _ptr(dyq), _ptr(ey), _ptr(dw), self._stream()),
+            float(xq.numel() + dyq.numel()), cv.net, self._geom_tag(cv) + ":f8"), "dg_conv3x3_wgrad_f8")
 
     def conv_wgrad_dense(self, cvs, slab, us, dws, dbs):
         """Weight / bias gradients of all convs of a dense block: conv k (``cvs[k-1]``: k*F -> F channels) reads ``slab[..., :k*F]``,

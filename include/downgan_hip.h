@@ -75,6 +75,12 @@ typedef struct dg_epilogue {
   void* out_q;
   void* out_qs;
   int64_t ldqs;
+  /* Second fp8 copy of the stored output for the fp8 WEIGHT GRADIENT (dg_conv3x3_wgrad_f8), whose contraction runs over pixels:
+   * out_u [pixel][ld of y] E4M3 bytes = stored value / 2^(out_ue[channel / 32] - 127), saturated at +-448, with ONE exponent
+   * byte per 32-channel block for the whole tensor (out_ue: Cout / 32 bytes of device memory, read by the launch; the caller
+   * derives them from an earlier pass, dg_block_exp_max).  Needs out_q (the copy is formed from the same rounded values). */
+  void* out_u;
+  const void* out_ue;
 } dg_epilogue;
 
 /* Geometry of ONE reference nn.Conv2d(Cin, Cout, kernel_size=3, stride, padding=1) layer
@@ -136,6 +142,15 @@ int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void* dy, float
  * g: Cin = Cout = nconv*128, stride 1, ldx / ldy = pixel strides of the two slabs; bf16; W % 32 == 0. */
 int dg_conv3x3_wgrad_dense(const dg_conv_geom* g, int nconv, const void* x, const void* dy,
                            float* const* dw, float* const* db, void* stream);
+
+/* fp8 weight gradient (BASELINE.json configs[4]; autograd of DoWnGAN/networks/critic.py:34-88 under GAN/wasserstein.py:52):
+ * dw[co][tap][ci] (fp32, accumulated into) += sum_p dy[p, co] * x[src(p, tap), ci] with E4M3 operands whose scale does not vary
+ * along pixels -- the contraction index -- : x = xq * 2^(ex[ci / 32] - 127), dy = dyq * 2^(ey[co / 32] - 127), one E8M0 exponent
+ * byte per 32-channel block of the whole tensor (device arrays of Cin / 32 and Cout / 32 bytes).  g->ldx / g->ldy are the pixel
+ * strides of xq / dyq in bytes (= elements); g->dtype = DG_BF16 (the precision the fp8 forms stand for).  Stride 1, Cin and Cout
+ * multiples of 128, W a multiple of 64, no pixel shuffle; anything else returns DG_ERR_BAD_SHAPE (callers keep the bf16 kernel). */
+int dg_conv3x3_wgrad_f8(const dg_conv_geom* g, const void* xq, const void* ex, const void* dyq, const void* ey, float* dw,
+                        void* stream);
   /* db (optional): bias gradient += sum_pixels dy */
 
 /* db[c] (fp32) += sum over rows of dy[row, c]  (bias gradient of a conv or Linear).  Row r is at
@@ -329,6 +344,12 @@ typedef struct dg_f8_operands {
   const void* wq;   /* fp8 weight pack [Nout][9][Cred] */
   const void* ws;   /* its scales [Nout][9][Cred/32] */
 } dg_f8_operands;
+/* out[b] = min(254, max over rows r of scales[r * ld + b] + margin), b < nblocks: the largest MXFP8 block exponent a tensor's
+ * 32-channel block b reached anywhere (scales = the E8M0 bytes dg_quant_mxfp8 / dg_epilogue.out_qs wrote) -- the per-block exponent
+ * of the uniform-scale copy (dg_epilogue.out_u) of the NEXT pass over the same tensor.  nblocks <= 64, a multiple of 4; `scratch`
+ * = 64 dwords of device memory the caller owns, ZERO on entry and left zero (one per stream that calls this concurrently). */
+int dg_block_exp_max(const void* scales, int64_t rows, int64_t ld, int nblocks, int margin, void* out, void* scratch, void* stream);
+
 int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int64_t ld, int C, void* q, int64_t ldq, void* scales,
                    int64_t ldqs, void* stream);   /* ldqs: scale bytes per row, 0 = C/32 */
 int dg_conv3x3_fwd_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* y, void* stream);

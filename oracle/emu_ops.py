@@ -85,7 +85,7 @@ class EmuOps:
         return torch.stack([(w[..., blk[c], g[c]] >> int(b[c])) & 1 for c in range(Cc)], dim=-1).bool()
 
     def _gather_gemm(self, d, x, w, y, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None,
-                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None):
+                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None):
         N = d.N
         xs = x.float()
         if d.src_ps:
@@ -151,6 +151,37 @@ class EmuOps:
             q, s, _ = self.mx_quant(y)
             out_q[0].copy_(q)
             out_q[1].copy_(s)
+        if out_u is not None:      # uniform-scale E4M3 copy (one exponent per 32-channel block of the whole tensor): dg_epilogue.out_u
+            assert out_q is not None
+            out_u[0].copy_(self.uq_quant(y, out_u[1])[0])
+
+    # ---- uniform-scale fp8 (csrc/gg_common.h epi64_pixel f_u; csrc/wgrad.hip wg3w_f8_kernel): E4M3 elements, ONE E8M0 exponent
+    # per 32-channel block for the whole tensor -- the operand format of the fp8 weight gradient, whose contraction runs over pixels
+    @staticmethod
+    def uq_quant(x, exps):
+        """x [..., C], exps uint8 [C/32] -> (q uint8 [..., C], dequantised fp32 [..., C]); a block holding a NaN / Inf is poisoned
+        (32 x 0x7F) like the MXFP8 copy."""
+        Cc = x.shape[-1]
+        v = x.float().reshape(-1, Cc // 32, 32)
+        scale = torch.ldexp(torch.ones(Cc // 32), exps.reshape(-1).int() - 127).view(1, -1, 1)
+        q8 = (v / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        q8 = torch.where(torch.isfinite(v.abs().amax(-1))[..., None], q8, torch.full_like(q8, 0x7F))
+        deq = q8.view(torch.float8_e4m3fn).float() * scale
+        return q8.reshape(x.shape), deq.reshape(x.shape)
+
+    @staticmethod
+    def uq_dequant(q, exps):
+        Cc = q.shape[-1]
+        scale = torch.ldexp(torch.ones(Cc // 32), exps.reshape(-1).int() - 127).view(1, -1, 1)
+        return (q.contiguous().view(torch.float8_e4m3fn).float().reshape(-1, Cc // 32, 32) * scale).reshape(q.shape)
+
+    def block_exp_max(self, scales, out, margin=1):
+        nb = scales.shape[-1]
+        out.copy_((scales.reshape(-1, nb).to(torch.int32).amax(0) + int(margin)).clamp(max=254).to(torch.uint8))
+
+    def conv_wgrad_f8(self, cv, xq, ex, dyq, ey, dw):
+        assert cv.stride == 1 and cv.Cin % 128 == 0 and cv.Cout % 128 == 0 and cv.W % 64 == 0 and not cv.pixel_shuffle
+        self.conv_wgrad(cv, self.uq_dequant(xq, ex), self.uq_dequant(dyq, ey), dw)
 
     # ---- MXFP8 (csrc/quant.hip): OCP E4M3 elements, one E8M0 scale per block of 32 consecutive channels (OCP MX layout);
     # scale = 2^(floor(log2 amax) - 8)
@@ -177,7 +208,12 @@ class EmuOps:
         scales.copy_(ss.view(scales.shape))
         return q, scales
 
+    f8_wgrad = True
+
     def f8_eligible(self, cv, kind):
+        if kind == "wgrad":
+            return (self.f8 and self.f8_wgrad and cv.net == "C" and cv.stride == 1 and not cv.pixel_shuffle and cv.Cin % 128 == 0
+                    and cv.Cout % 128 == 0 and cv.W % 64 == 0)
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
         nets = ("C", "G") if (self.f8_generator and kind == "fwd") else ("C",)
         return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle

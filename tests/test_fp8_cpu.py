@@ -86,3 +86,62 @@ def test_generator_fp8_trunk_on_emulated_ops():
     d = (outs[True][2] - outs[False][2]).norm() / outs[False][2].norm()
     assert 0 < float(d) < 0.1, float(d)                                        # trunk went through fp8 and stayed close
     assert float((outs[True][0] - outs[False][0]).norm() / outs[False][0].norm()) < 0.1
+
+
+def test_uniform_scale_copy_and_block_exponents():
+    """The operand format of the fp8 weight gradient (oracle/emu_ops.py::uq_quant, csrc/gg_common.h epi64_pixel f_u): E4M3 with one
+    exponent per 32-channel block of the whole tensor; block_exp_max = the largest MXFP8 block exponent + margin."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 5, 7, 256, generator=g) * torch.logspace(-3, 1, 256)
+    _, s, _ = EmuOps.mx_quant(x)
+    exps = torch.zeros(8, dtype=torch.uint8)
+    EmuOps("f32").block_exp_max(s, exps, margin=1)
+    assert torch.equal(exps, (s.reshape(-1, 8).int().amax(0) + 1).to(torch.uint8))
+    q, d = EmuOps.uq_quant(x, exps)
+    scale = torch.ldexp(torch.ones(8), exps.int() - 127).repeat_interleave(32)
+    assert float((x.abs() / scale).max()) < 256                          # margin 1: the largest element sits below 2^8
+    err = (d - x).abs()
+    assert bool((err <= x.abs() * 2.0 ** -4 + scale * 2.0 ** -10).all())   # E4M3: 3 mantissa bits, subnormals down to 2^-9
+    assert torch.equal(EmuOps.uq_dequant(q, exps), d)
+    x[1, 2, 3, 40] = float("inf")
+    q2, _ = EmuOps.uq_quant(x, exps)
+    assert bool((q2[1, 2, 3, 32:64] == 0x7F).all()) and int((q2 == 0x7F).sum()) >= 32
+
+
+def test_engine_fp8_weight_gradients_after_the_first_pass():
+    """fp8 mode, emulated: the eligible critic layer (128 -> 256 at 64x64: stride 1, rows of 64 pixels) takes its weight gradient
+    from the uniform-scale fp8 copies once the exponents of a role exist -- the real pass of the first iteration still uses the bf16
+    kernel, the fake pass and the penalty's tangent pass of the SECOND iteration use dg_conv3x3_wgrad_f8 -- and the gradients stay
+    close to the ones of the fp8 mode with bf16 weight gradients."""
+    from downgan_amd import synthetic
+    from downgan_amd.engine import HyperParams, TrainEngine
+    from downgan_amd.layout import nchw_to_nhwc_padded
+    torch.set_num_threads(4)
+    B, S, F_, cin, nrb = 1, 16, 128, 2, 1
+    res = {}
+    for wg8 in (False, True):
+        ops = EmuOps("f32", f8_critic=True)
+        ops.f8_wgrad = wg8
+        calls = []
+        real = ops.conv_wgrad_f8
+        ops.conv_wgrad_f8 = lambda cv, *a, _r=real: (calls.append((cv.Cin, cv.Cout, cv.H)), _r(cv, *a))[1]
+        eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B), num_res_blocks=nrb)
+        eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))
+        eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
+        assert eng.C.wg8 == ([False, False, True, False, False, False, False, False] if wg8 else [False] * 8)
+        coarse, fine = synthetic.tiles(B, cin, S)
+        xc = nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.float32)
+        xf = nchw_to_nhwc_padded(torch.from_numpy(fine), 16, torch.float32)
+        per_iter = []
+        for it in range(2):
+            n0 = len(calls)
+            eng.critic_iteration(xc, xf, torch.from_numpy(synthetic.alpha(B, it)), apply_update=False)
+            per_iter.append(len(calls) - n0)
+        res[wg8] = (eng.C.P.g.clone(), per_iter, eng.read_scalars())
+    assert res[False][1] == [0, 0]
+    # iteration 0: real pass bf16 (no exponents yet), fake pass fp8, tangent pass bf16 (its role has no exponents yet); iteration 1: all three
+    assert res[True][1] == [1, 3], res[True][1]
+    ga, gb = res[False][0], res[True][0]
+    assert 0 < float((ga - gb).norm()) < 0.05 * float(ga.norm())
+    for k in ("c_real_mean", "c_fake_mean", "gp_ret"):
+        assert res[False][2][k] == res[True][2][k], k                       # the forward and the penalty's value do not depend on it

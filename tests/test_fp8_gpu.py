@@ -243,3 +243,114 @@ def test_mirrors_accept_fp8_dtype():
     out.update(tr._generator_train_iteration(torch.from_numpy(coarse), torch.from_numpy(fine), _reuse_g=True))
     assert tr._engine.C.f8 and tr._engine.G.f8
     assert all(math.isfinite(v) for v in out.values()), out
+
+
+def _quant_uniform(t, exps):
+    """E4M3 copy of t [.., C] with one exponent byte per 32-channel block of the WHOLE tensor (q = t / 2^(e - 127), saturated at
+    +-448, round to nearest even -- torch's float8_e4m3fn cast), and the fp32 values it stands for."""
+    C = t.shape[-1]
+    scale = torch.pow(2.0, exps.to(torch.float32) - 127.0).repeat_interleave(32)[:C]
+    q = (t.float() / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), q.float() * scale
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 64, 128, 128), (1, 8, 128, 256, 128), (1, 12, 64, 128, 384), (3, 5, 64, 256, 256)])
+def test_wgrad_f8_uniform_scales(cfg):
+    """dg_conv3x3_wgrad_f8 (contraction over pixels on v_mfma_scale_f32_32x32x64_f8f6f4; operands E4M3 with one exponent per
+    32-channel block of the whole tensor) against the emulation's fp32 weight gradient of the DEQUANTISED operands: products of two
+    E4M3 values are exact in fp32, so only the summation order differs (1e-5 of the largest entry).  Accumulates into dw.
+    Reference math: autograd of DoWnGAN/networks/critic.py:34-88 (weight gradient of a 3x3 conv, padding 1)."""
+    from oracle.emu_ops import EmuOps
+    N, H, W, ci, co = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    hip, emu = HipOps("bf16"), EmuOps("f32")
+    cv = Conv(N, H, W, ci, co)
+    x = torch.randn(N, H, W, ci, generator=g) * torch.logspace(-2, 1, ci).view(1, 1, 1, ci)        # channels of very different size
+    dy = torch.randn(N, H, W, co, generator=g) * 0.01
+    # exponents: the block's floor(log2 amax) - 8 + 127 (the OCP MX rule applied to the whole tensor), one block deliberately too small (saturates)
+    def exps(t):
+        am = t.abs().reshape(-1, t.shape[-1] // 32, 32).amax(dim=(0, 2))
+        return (torch.floor(torch.log2(am)) - 8 + 127).to(torch.uint8)
+    ex, ey = exps(x), exps(dy)
+    ex[0] -= 2
+    xq, xd = _quant_uniform(x, ex)
+    dq, dd = _quant_uniform(dy, ey)
+    dw_ref = torch.randn(co * 9 * ci, generator=g) * 0.1
+    dw = dw_ref.clone().cuda()
+    emu.conv_wgrad(cv, xd, dd, dw_ref)
+    hip.conv_wgrad_f8(cv, xq.cuda(), ex.cuda(), dq.cuda(), ey.cuda(), dw)
+    scale = float(dw_ref.abs().max())
+    err = float((dw.cpu() - dw_ref).abs().max())
+    assert err <= 1e-5 * scale * 8, (cfg, err, scale)
+    # operands that are channel slices of wider tensors (pixel stride > channels)
+    xw = torch.zeros(N, H, W, ci + 128, dtype=torch.uint8); xw[..., 64:64 + ci] = xq
+    dw2 = torch.zeros(co * 9 * ci).cuda()
+    hip.conv_wgrad_f8(cv, xw.cuda()[..., 64:64 + ci], ex.cuda(), dq.cuda(), ey.cuda(), dw2)
+    dw3 = torch.zeros(co * 9 * ci); emu.conv_wgrad(cv, xd, dd, dw3)
+    assert float((dw2.cpu() - dw3).abs().max()) <= 1e-5 * float(dw3.abs().max()) * 8, cfg
+    # shapes the kernel does not take are refused, not mis-computed
+    for bad in (Conv(N, H, 32, ci, co), Conv(N, H, W, ci, co, 2), Conv(N, H, W, 64, co)):
+        with pytest.raises((RuntimeError, AssertionError)):
+            hip.conv_wgrad_f8(bad, torch.zeros(bad.N, bad.H, bad.W, bad.Cin, dtype=torch.uint8).cuda(), torch.zeros(max(bad.Cin // 32, 1), dtype=torch.uint8).cuda(),
+                              torch.zeros(bad.N, bad.Ho, bad.Wo, co, dtype=torch.uint8).cuda(), ey.cuda(), torch.zeros(co * 9 * bad.Cin).cuda())
+
+
+@pytest.mark.parametrize("case", ["fp8_s2_forward", "fp8_s2_dgrad_classes", "fp8_s1_forward_mask_bits", "bf16_halo", "general_epilogue"])
+def test_fused_uniform_scale_copy_equals_quantised_store(case):
+    """dg_epilogue.out_u / out_ue: the uniform-scale E4M3 copy (operand of dg_conv3x3_wgrad_f8) a conv epilogue writes beside its
+    bf16 output and the MXFP8 copy is bit-identical to quantising the STORED tensor with the given per-block exponents
+    (oracle/emu_ops.py::uq_quant) -- on the launches that produce the critic's activations (stride-2 fp8 forward), adjoints
+    (merged stride-2 fp8 data gradient) and the penalty's tangents (fp8 forward with the 1-bit mask)."""
+    from oracle.emu_ops import EmuOps
+    g = torch.Generator().manual_seed(77)
+    f8 = case.startswith("fp8")
+    hip = HipOps("bf16", f8_critic=True)
+    st = 2 if "s2" in case else 1
+    cv = Conv(2, 32, 48, 128, 256, st, False, net="C" if f8 else "")
+    qpair = lambda shape: (torch.zeros(shape, dtype=torch.uint8).cuda(), torch.zeros(tuple(shape[:-1]) + (shape[-1] // 32,), dtype=torch.uint8).cuda())
+    if case == "fp8_s2_dgrad_classes":
+        dy = (torch.randn(hip.out_shape(cv), generator=g) * 1e-3).to(torch.bfloat16).cuda()
+        wd = (torch.randn(cv.Cout * 9 * cv.Cin, generator=g) * 0.05).to(torch.bfloat16).cuda()
+        mb = torch.randint(0, 1 << 15, hip.bits_shape((cv.N, cv.H, cv.W, cv.Cin)), generator=g).to(torch.int16).cuda()
+        y = torch.zeros(cv.N, cv.H, cv.W, cv.Cin, dtype=torch.bfloat16).cuda()
+        exps = torch.tensor([127 - 12, 127 - 14, 127 - 13, 127 - 20], dtype=torch.uint8)      # the last block saturates
+        oq, u = qpair(y.shape), torch.zeros(y.shape, dtype=torch.uint8).cuda()
+        hip.conv_dgrad(cv, dy, wd, y, mask_bits=mb, mask_slope=0.2, out_q=oq, out_u=(u, exps.cuda()))
+        assert hip.lib.dg_last_conv_kernels() == 32
+    else:
+        x = torch.randn(cv.N, cv.H, cv.W, cv.Cin, generator=g).to(torch.bfloat16).cuda()
+        w = (torch.randn(cv.Cout * 9 * cv.Cin, generator=g) * 0.05).to(torch.bfloat16).cuda()
+        y = torch.zeros(hip.out_shape(cv), dtype=torch.bfloat16).cuda()
+        exps = (127 - 7 + torch.arange(cv.Cout // 32) % 3).to(torch.uint8)
+        exps[1] = 127 - 12                                                                    # saturates
+        oq, u = qpair(y.shape), torch.zeros(y.shape, dtype=torch.uint8).cuda()
+        ob = torch.zeros(hip.bits_shape(y.shape), dtype=torch.int16).cuda()
+        if case == "general_epilogue":
+            r1 = torch.randn(y.shape, generator=g).to(torch.bfloat16).cuda()
+            hip.conv_fwd(cv, x, w, y, act=0.2, r1=r1, s1=0.5, out_q=oq, out_u=(u, exps.cuda()))
+        elif case == "fp8_s1_forward_mask_bits":
+            mb = torch.randint(0, 1 << 15, hip.bits_shape(y.shape), generator=g).to(torch.int16).cuda()
+            hip.conv_fwd(cv, x, w, y, mask_bits=mb, mask_slope=0.2, out_q=oq, out_u=(u, exps.cuda()))
+        else:
+            hip.conv_fwd(cv, x, w, y, act=0.2, out_bits=ob, out_q=oq, out_u=(u, exps.cuda()))
+        assert hip.lib.dg_last_conv_kernels() == (32 if f8 else 8)
+    q_ref, _ = EmuOps.uq_quant(y.cpu(), exps)
+    assert float(y.float().abs().max()) > 0 and int((q_ref & 0x7f == 0x7e).sum()) > 0          # something did saturate at 448
+    assert torch.equal(u.cpu(), q_ref), int((u.cpu() != q_ref).sum())
+    s_ref = hip.quant_mxfp8(y)
+    assert torch.equal(oq[0], s_ref[0]) and torch.equal(oq[1], s_ref[1])                       # the MXFP8 copy is unchanged by it
+
+
+def test_block_exp_max_kernel():
+    g = torch.Generator().manual_seed(5)
+    hip = HipOps("bf16")
+    for rows, nb, ld in ((1000, 4, 4), (77777, 8, 8), (4096, 32, 32), (333, 4, 20), (50000, 20, 20)):
+        sc = torch.randint(90, 140, (rows, ld), generator=g).to(torch.uint8)
+        r, b = int(torch.randint(0, rows, (1,), generator=g)), int(torch.randint(0, nb, (1,), generator=g))
+        sc[r, b] = 200
+        dev = sc.cuda()
+        out = torch.zeros(nb, dtype=torch.uint8).cuda()
+        for margin in (0, 1):
+            hip.block_exp_max(dev[:, :nb], out, margin=margin)
+            assert torch.equal(out.cpu(), (sc[:, :nb].int().amax(0) + margin).to(torch.uint8)), (rows, nb, ld, margin)
+        assert int(hip._exp_scratch.abs().sum()) == 0                  # the scratch is left zero
