@@ -61,6 +61,14 @@ class FieldPlanes(C.Structure):
     _fields_ = [("plane", C.c_void_p * MAX_FIELDS), ("mean", C.c_float * MAX_FIELDS), ("inv_std", C.c_float * MAX_FIELDS), ("c", C.c_int)]
 
 
+EXP_BATCH_MAX = 16
+
+
+class ExpBatch(C.Structure):
+    _fields_ = [("scales", C.c_void_p * EXP_BATCH_MAX), ("rows", C.c_int64 * EXP_BATCH_MAX), ("ld", C.c_int64 * EXP_BATCH_MAX),
+                ("nblocks", C.c_int * EXP_BATCH_MAX), ("out", C.c_void_p * EXP_BATCH_MAX), ("n", C.c_int)]
+
+
 FINITE_MAX = 8
 
 
@@ -115,6 +123,8 @@ _PROTOS = {
     "dg_gather_samples": [_i, _vp, _i64, _i, _vp, _i, _vp, _i, _vp],
     "dg_quant_mxfp8": [_i, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i64, _vp],
     "dg_block_exp_max": [_vp, _i64, _i64, _i, _i, _vp, _vp, _vp],
+    "dg_block_exp_max_batch": [C.POINTER(ExpBatch), _i, _vp, _vp],
+    "dg_quant_uniform": [_i, _vp, _i64, _i64, _i, _vp, _vp, _i64, _vp],
     "dg_conv3x3_fwd_f8": [C.POINTER(ConvGeom), C.POINTER(Epilogue), C.POINTER(F8Operands), _vp, _vp],
     "dg_conv3x3_dgrad_f8": [C.POINTER(ConvGeom), C.POINTER(Epilogue), C.POINTER(F8Operands), _vp, _vp],
     "dg_moments": [_vp, _i64, _vp, _vp],

@@ -79,40 +79,114 @@ extern "C" int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int6
   return dg_check_launch();
 }
 
-// ---- per-block maximum of the MXFP8 scale bytes of a tensor (rows x nblocks bytes): the exponents of its uniform-scale copy.
-// Threads walk dwords of the byte matrix (nblocks is a multiple of 4: channel counts are multiples of 128) with a running
-// byte-wise maximum, then one atomicMax per block into the caller's 64-dword scratch (zero at rest: the finish kernel clears it).
-__global__ void __launch_bounds__(256) block_exp_max_kernel(const unsigned* __restrict__ sc, long long rows, long long ld4, int nb4,
-                                                            unsigned* __restrict__ tmp) {
+// ---- per-block maximum of the MXFP8 scale bytes of up to DG_EXP_BATCH_MAX tensors (rows x nblocks bytes each) in ONE launch: the
+// exponents of their uniform-scale copies.  blockIdx.y = tensor.  Threads walk dwords of the byte matrix (nblocks is a multiple of 4:
+// channel counts are multiples of 128) with a running byte-wise maximum, reduce through LDS, then ONE atomicMax per block and
+// workgroup into the caller's scratch (64 dwords per tensor, zero at rest: the finish kernel clears what it read).  (One atomic
+// per THREAD -- 2 M atomics on <= 64 addresses per call -- cost the fp8 train step +40 ms.)
+__global__ void __launch_bounds__(256) block_exp_max_kernel(const dg_exp_batch b, unsigned* __restrict__ tmp_all) {
+  const int ti = blockIdx.y;
+  const unsigned* __restrict__ sc = reinterpret_cast<const unsigned*>(b.scales[ti]);
+  const long long rows = b.rows[ti], ld4 = b.ld[ti] / 4;
+  const int nb4 = b.nblocks[ti] / 4;
+  unsigned* tmp = tmp_all + ti * 64;
   const int col = threadIdx.x % nb4, sub = threadIdx.x / nb4, nsub = 256 / nb4;
-  if (sub >= nsub) return;
   unsigned m = 0;
-  for (long long r = (long long)blockIdx.x * nsub + sub; r < rows; r += (long long)gridDim.x * nsub) {
+  for (long long r = (long long)blockIdx.x * nsub + sub; sub < nsub && r < rows; r += (long long)gridDim.x * nsub) {
     const unsigned v = sc[r * ld4 + col];
     unsigned r4 = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { const unsigned x = (v >> (8 * b)) & 0xffu, y = (m >> (8 * b)) & 0xffu; r4 |= (x > y ? x : y) << (8 * b); }
+    for (int k = 0; k < 4; ++k) { const unsigned x = (v >> (8 * k)) & 0xffu, y = (m >> (8 * k)) & 0xffu; r4 |= (x > y ? x : y) << (8 * k); }
     m = r4;
   }
+  __shared__ unsigned sm[256];
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  if ((int)threadIdx.x < nb4) {
+    unsigned r4 = 0;
+    for (int k = 0; k < nsub; ++k) {
+      const unsigned v = sm[k * nb4 + threadIdx.x];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) atomicMax(tmp + col * 4 + b, (m >> (8 * b)) & 0xffu);
+      for (int q = 0; q < 4; ++q) { const unsigned x = (v >> (8 * q)) & 0xffu, y = (r4 >> (8 * q)) & 0xffu; r4 = (r4 & ~(0xffu << (8 * q))) | ((x > y ? x : y) << (8 * q)); }
+    }
+    if (r4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicMax(tmp + threadIdx.x * 4 + q, (r4 >> (8 * q)) & 0xffu);
+    }
+  }
 }
-__global__ void block_exp_finish_kernel(unsigned* __restrict__ tmp, int nblocks, int margin, unsigned char* __restrict__ out) {
-  const int b = threadIdx.x;
-  if (b < nblocks) { const unsigned v = tmp[b] + (unsigned)margin; out[b] = (unsigned char)(v > 254u ? 254u : v); tmp[b] = 0u; }
+__global__ void block_exp_finish_kernel(const dg_exp_batch b, unsigned* __restrict__ tmp_all, int margin) {
+  const int ti = blockIdx.x, k = threadIdx.x;
+  unsigned* tmp = tmp_all + ti * 64;
+  if (k < b.nblocks[ti]) {
+    const unsigned v = tmp[k] + (unsigned)margin;
+    reinterpret_cast<unsigned char*>(b.out[ti])[k] = (unsigned char)(v > 254u ? 254u : v);
+    tmp[k] = 0u;
+  }
+}
+
+extern "C" int dg_block_exp_max_batch(const dg_exp_batch* b, int margin, void* scratch, void* stream) {
+  if (!b || !scratch) return DG_ERR_BAD_ARG;
+  if (b->n <= 0 || b->n > DG_EXP_BATCH_MAX || margin < 0 || margin > 8 || reinterpret_cast<uintptr_t>(scratch) % 4) return DG_ERR_BAD_SHAPE;
+  long long maxwg = 1;
+  for (int i = 0; i < b->n; ++i) {
+    if (!b->scales[i] || !b->out[i]) return DG_ERR_BAD_ARG;
+    const int nb = b->nblocks[i];
+    if (b->rows[i] <= 0 || nb <= 0 || nb > 64 || nb % 4 || b->ld[i] < nb || b->ld[i] % 4 || reinterpret_cast<uintptr_t>(b->scales[i]) % 4) return DG_ERR_BAD_SHAPE;
+    const long long nsub = 256 / (nb / 4);
+    long long nwg = (b->rows[i] + nsub * 64 - 1) / (nsub * 64);
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  if (maxwg > 512) maxwg = 512;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(block_exp_max_kernel, dim3((unsigned)maxwg, (unsigned)b->n), dim3(256), 0, st, *b, (unsigned*)scratch);
+  hipLaunchKernelGGL(block_exp_finish_kernel, dim3((unsigned)b->n), dim3(64), 0, st, *b, (unsigned*)scratch, margin);
+  return dg_check_launch();
 }
 
 extern "C" int dg_block_exp_max(const void* scales, int64_t rows, int64_t ld, int nblocks, int margin, void* out, void* scratch, void* stream) {
-  if (!scales || !out || !scratch) return DG_ERR_BAD_ARG;
-  if (rows <= 0 || nblocks <= 0 || nblocks > 64 || nblocks % 4 || ld < nblocks || ld % 4 || margin < 0 || margin > 8) return DG_ERR_BAD_SHAPE;
-  if (reinterpret_cast<uintptr_t>(scales) % 4 || reinterpret_cast<uintptr_t>(scratch) % 4) return DG_ERR_BAD_ARG;
+  dg_exp_batch b{};
+  b.n = 1; b.scales[0] = scales; b.rows[0] = rows; b.ld[0] = ld; b.nblocks[0] = nblocks; b.out[0] = out;
+  return dg_block_exp_max_batch(&b, margin, scratch, stream);
+}
+
+// ---- stand-alone uniform-scale quantiser (the conv epilogues write this form themselves, dg_epilogue.out_u; this is for the one
+// adjoint that does not come out of a conv: the FC's input gradient): q[r][c] = E4M3(src[r][c] / 2^(exps[c / 32] - 127)), a block
+// that holds a NaN / Inf poisoned like the MXFP8 copy.  One thread = one 32-channel block of one row.
+template <typename T>
+__global__ void __launch_bounds__(256) quant_uniform_kernel(const T* __restrict__ src, long long rows, long long ld, int C,
+                                                            const unsigned char* __restrict__ exps, unsigned char* __restrict__ q, long long ldq) {
+  const int nb = C >> 5;
+  const long long total = rows * nb;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const long long r = t / nb;
+    const int b = (int)(t - r * nb);
+    float v[32];
+    QLoad<T>::run(src + r * ld + b * 32, v);
+    QLoad<T>::run(src + r * ld + b * 32 + 16, v + 16);
+    const unsigned a0 = mx_amax_bits16(v), a1 = mx_amax_bits16(v + 16);
+    const unsigned ab = a0 > a1 ? a0 : a1;
+    const float inv = mx_inv_scale((int)exps[b]);
+    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + b * 32) = mx_poison(pack_fp8x16(v, inv), ab);
+    *reinterpret_cast<q_u32x4_t*>(q + r * ldq + b * 32 + 16) = mx_poison(pack_fp8x16(v + 16, inv), ab);
+  }
+}
+
+extern "C" int dg_quant_uniform(int src_dtype, const void* src, int64_t rows, int64_t ld, int C, const void* exps, void* q, int64_t ldq,
+                                void* stream) {
+  if (!src || !q || !exps) return DG_ERR_BAD_ARG;
+  if (rows <= 0 || C <= 0 || C % 128 || ld < C || ldq < C || ldq % 16) return DG_ERR_BAD_SHAPE;
+  if ((src_dtype == DG_BF16 && ld % 8) || (src_dtype == DG_F32 && ld % 4)) return DG_ERR_BAD_SHAPE;
+  const long long total = (long long)rows * (C / 32);
+  long long nb = (total + 255) / 256;
+  if (nb > 65536) nb = 65536;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int nb4 = nblocks / 4, nsub = 256 / nb4;
-  long long nwg = (rows + (long long)nsub * 64 - 1) / ((long long)nsub * 64);
-  if (nwg > 2048) nwg = 2048;
-  if (nwg < 1) nwg = 1;
-  hipLaunchKernelGGL(block_exp_max_kernel, dim3((unsigned)nwg), dim3(256), 0, st, (const unsigned*)scales, (long long)rows, (long long)(ld / 4), nb4,
-                     (unsigned*)scratch);
-  hipLaunchKernelGGL(block_exp_finish_kernel, dim3(1), dim3(64), 0, st, (unsigned*)scratch, nblocks, margin, (unsigned char*)out);
+  if (src_dtype == DG_BF16)
+    hipLaunchKernelGGL(quant_uniform_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)src, (long long)rows, (long long)ld, C,
+                       (const unsigned char*)exps, (unsigned char*)q, (long long)ldq);
+  else if (src_dtype == DG_F32)
+    hipLaunchKernelGGL(quant_uniform_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)src, (long long)rows, (long long)ld, C,
+                       (const unsigned char*)exps, (unsigned char*)q, (long long)ldq);
+  else return DG_ERR_BAD_DTYPE;
   return dg_check_launch();
 }

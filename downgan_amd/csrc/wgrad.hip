@@ -934,15 +934,20 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
 // Tile and schedule as wg3w_kernel (128 adjoint x 128 input channels x 3 taps, DMA-staged three-buffer ring, one barrier per
 // step) with 64-pixel steps: tile rows are 128 B, a DMA piece = 8 rows, LDS 3 x 17 KB.  The 32-byte chunk index of a row is
 // XOR-ed with (row >> 1) & 3 on the source side of the DMA: the eight rows of a transposing read then cover all 64 banks.
-// Stride 1, channel counts that are multiples of 128, rows of a multiple of 64 pixels.
+// Strides 1 and 2, channel counts that are multiples of 128, output rows of a multiple of 64 pixels.
 typedef __attribute__((ext_vector_type(8))) int i32x8w_t;
 typedef __attribute__((ext_vector_type(2))) int i32x2w_t;
 typedef __attribute__((address_space(3))) i32x2w_t* lds_i32x2_ptr;
 
+template <bool S2>
 __global__ __launch_bounds__(256, 2) void wg3w_f8_kernel(const WGArgs a) {
   constexpr int BCO = 128, BCI = 128, KP = 64, ROWB = 128;
-  constexpr int XROWS = KP + 2, UPIECES = KP / 8, XPIECES = KP / 8 + 1;       // 8 adjoint pieces, 9 input pieces (rows 66..71 never read)
-  constexpr int SU_B = KP * ROWB, SX_B = XPIECES * 8 * ROWB, BUFB = SU_B + SX_B;
+  // x tile: KP + 2 rows (stride 1) / 2 KP + 1 rows (S2: input columns 2wo - 1 .. 2wo + 127, tap s of output pixel k = row 2k + s) in
+  // DMA pieces of 8 rows.  S2: the eight rows of a transposing read are two apart, i.e. all in the same 128-byte half of the 256-byte
+  // bank span -- consecutive pieces are therefore skewed by one row (piece pitch 1152 B): the rows of a read that fall into the next
+  // piece land in the other half, and the 32-byte chunk XOR separates the (at most four) rows inside a half.
+  constexpr int XK = S2 ? 2 : 1, XROWS = S2 ? 2 * KP + 1 : KP + 2, NXW = S2 ? 4 : 2, XPIECES = 4 * NXW + 1, XPITCH = S2 ? 1152 : 1024;
+  constexpr int SU_B = KP * ROWB, SX_B = XPIECES * XPITCH, BUFB = SU_B + SX_B;
   extern __shared__ __attribute__((aligned(16))) unsigned char wg8_dsm[];          // 3 * BUFB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
@@ -981,27 +986,28 @@ __global__ __launch_bounds__(256, 2) void wg3w_f8_kernel(const WGArgs a) {
   };
   int s_wo = pbeg % a.Wo, s_ho, s_n;
   { const int t = pbeg / a.Wo; s_ho = t % a.Ho; s_n = t / a.Ho; }
-  // tile t (64 output pixels of one row + the 66 input pixels under them) -> buffer buf.  A lane whose input pixel lies outside
+  // tile t (64 output pixels of one row + the input pixels under them) -> buffer buf.  A lane whose input pixel lies outside
   // the image gets the out-of-range offset (the range check looks at the lane offset only: the load returns zeros).
   auto issue = [&](int buf, int t) {
     const long long ub = ((long long)(s_n * a.Ho + s_ho) * a.Wo + s_wo) * a.ldu + co0;
-    const int hi = s_ho + dr;
+    const int hi = XK * s_ho + dr;
     const bool row_ok = (unsigned)hi < (unsigned)a.H;
-    const int wi0 = s_wo - 1;                                   // input column of tile row 0
+    const int wi0 = XK * s_wo - 1;                              // input column of tile row 0
     const long long xb = ((long long)(s_n * a.H + (row_ok ? hi : 0)) * a.W + wi0) * a.ldx + ci0;
     const i32x4w_t rsU = make_rs(U + ub), rsX = make_rs(X + xb);
     const unsigned m0b = lds0 + (unsigned)buf * BUFB;
 #pragma unroll
     for (int j = 0; j < 2; ++j) dma(m0b + (unsigned)(wave + 4 * j) * 1024u, ulane, rsU, (unsigned)((wave + 4 * j) * 8 * (int)a.ldu));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NXW; ++j) {
       const int row0 = 8 * (wave + 4 * j);
       const unsigned vo = (row_ok && (unsigned)(wi0 + row0 + drow) < (unsigned)a.W) ? xlane : WG_OOB_OFF;
-      dma(m0b + SU_B + (unsigned)(wave + 4 * j) * 1024u, vo, rsX, (unsigned)(row0 * (int)a.ldx));
+      dma(m0b + SU_B + (unsigned)(wave + 4 * j) * (unsigned)XPITCH, vo, rsX, (unsigned)(row0 * (int)a.ldx));
     }
-    if ((t & 3) == wave) {                                      // rows 64 .. 71 (64, 65 are read): one wave per step, in turn
-      const unsigned vo = (row_ok && drow < XROWS - KP && (unsigned)(wi0 + KP + drow) < (unsigned)a.W) ? xlane : WG_OOB_OFF;
-      dma(m0b + SU_B + (unsigned)(XPIECES - 1) * 1024u, vo, rsX, (unsigned)(KP * (int)a.ldx));
+    if ((t & 3) == wave) {                                      // the last piece (2 / 1 of its rows are read): one wave per step, in turn
+      constexpr int R0 = 8 * (XPIECES - 1);
+      const unsigned vo = (row_ok && drow < XROWS - R0 && (unsigned)(wi0 + R0 + drow) < (unsigned)a.W) ? xlane : WG_OOB_OFF;
+      dma(m0b + SU_B + (unsigned)(XPIECES - 1) * (unsigned)XPITCH, vo, rsX, (unsigned)(R0 * (int)a.ldx));
     }
     s_wo += KP;
     if (s_wo >= a.Wo) { s_wo = 0; if (++s_ho == a.Ho) { s_ho = 0; ++s_n; } }
@@ -1021,16 +1027,21 @@ __global__ __launch_bounds__(256, 2) void wg3w_f8_kernel(const WGArgs a) {
   const int bu = (32 * h + prow) * ROWB + (((prow >> 1) & 3) << 5) + low;            // adjoint fragment f, read q: (bu ^ (f << 5)) + q * 8 * ROWB
   int bxs[3];
 #pragma unroll
-  for (int s = 0; s < 3; ++s) bxs[s] = SU_B + (32 * h + prow + s) * ROWB + ((wave ^ (((prow + s) >> 1) & 3)) << 5) + low;
+  for (int s = 0; s < 3; ++s) {
+    const int row = XK * (32 * h + prow) + s;                  // tile row of this lane's pixel for read q = 0 (read q: + 8 XK q rows)
+    bxs[s] = SU_B + row * ROWB + (S2 ? (row >> 3) * (XPITCH - 1024) : 0) + ((wave ^ ((row >> 1) & 3)) << 5) + low;
+  }
+  constexpr int XQ = 8 * XK * ROWB + (S2 ? 2 * (XPITCH - 1024) : 0);      // byte step between the reads q, q + 1 of an input fragment
   // exponent bytes: adjoint fragment f = 32-channel block co0 / 32 + f, this wave's input columns = block ci0 / 32 + wave
   const unsigned eu4 = *reinterpret_cast<const unsigned*>(a.eu + (co0 >> 5));
   const int sxb = (int)a.ex[(ci0 >> 5) + wave];
 
   issue(0, 0);
   if (nsteps > 1) issue(1, 1);
-  auto wait_older = [&](bool newest_in_flight) {
+  auto wait_older = [&](bool newest_in_flight) {        // a tile = NXW + 2 or NXW + 3 pieces per wave: everything older than the newest has landed
     if (!newest_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // a tile = 4 or 5 pieces per wave: everything older than the newest has landed
+    else if (S2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   };
   wait_older(nsteps > 1);
   __syncthreads();
@@ -1040,24 +1051,24 @@ __global__ __launch_bounds__(256, 2) void wg3w_f8_kernel(const WGArgs a) {
     int nb = cur + 2; if (nb >= 3) nb -= 3;
     if (ahead) issue(nb, ks + 2);            // buffer (ks + 2) % 3 was last read in step ks - 1, behind that step's barrier
     const unsigned char* sb = wg8_dsm + cur * BUFB;
-    auto read_frag = [&](int off) {
+    auto read_frag = [&](int off, int qstep) {
       i32x8w_t v;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const i32x2w_t t = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2_ptr)(sb + off + q * 8 * ROWB));
+        const i32x2w_t t = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2_ptr)(sb + off + q * qstep));
         v[2 * q] = t[0]; v[2 * q + 1] = t[1];
       }
       return v;
     };
     i32x8w_t fb[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) fb[s] = read_frag(bxs[s]);
+    for (int s = 0; s < 3; ++s) fb[s] = read_frag(bxs[s], XQ);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       // 192 accumulator + 24 input-fragment registers leave room for ONE adjoint fragment: its read latency is in the open (the
       // second workgroup of the CU covers it); a second one in flight spilled 13 registers
       __builtin_amdgcn_sched_barrier(0);
-      const i32x8w_t fa = read_frag(bu ^ (f << 5));
+      const i32x8w_t fa = read_frag(bu ^ (f << 5), 8 * ROWB);
       __builtin_amdgcn_sched_barrier(0);
       const int sua = (int)((eu4 >> (8 * f)) & 0xffu);
 #pragma unroll
@@ -1097,13 +1108,14 @@ extern "C" int dg_conv3x3_wgrad_f8(const dg_conv_geom* g, const void* xq, const 
                                    void* stream) {
   if (!g || !xq || !ex || !dyq || !ey || !dw) return DG_ERR_BAD_ARG;
   if (g->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;               // (the dtype of the tensors the fp8 forms stand for)
-  if (g->N <= 0 || g->H <= 0 || g->W <= 0 || g->stride != 1 || g->pixel_shuffle) return DG_ERR_BAD_SHAPE;
-  if (g->Cin <= 0 || g->Cout <= 0 || g->Cin % 128 || g->Cout % 128 || g->W % 64) return DG_ERR_BAD_SHAPE;
+  if (g->N <= 0 || g->H <= 0 || g->W <= 0 || (g->stride != 1 && g->stride != 2) || g->pixel_shuffle) return DG_ERR_BAD_SHAPE;
+  if (g->stride == 2 && ((g->H | g->W) & 1)) return DG_ERR_BAD_SHAPE;
+  if (g->Cin <= 0 || g->Cout <= 0 || g->Cin % 128 || g->Cout % 128 || (g->W / g->stride) % 64) return DG_ERR_BAD_SHAPE;
   if (g->ldx < g->Cin || g->ldy < g->Cout || g->ldx % 16 || g->ldy % 16) return DG_ERR_BAD_SHAPE;
   WGArgs a{};
   a.x = xq; a.u = dyq; a.dw = dw; a.ldx = g->ldx; a.ldu = g->ldy;
   a.ex = (const unsigned char*)ex; a.eu = (const unsigned char*)ey;
-  a.H = g->H; a.W = g->W; a.stride = 1; a.Ho = g->H; a.Wo = g->W;
+  a.H = g->H; a.W = g->W; a.stride = g->stride; a.Ho = g->H / g->stride; a.Wo = g->W / g->stride;
   a.Cin = g->Cin; a.Cout = g->Cout; a.u_ps = 0; a.cps_chunks = 1;
   const long long mp = (long long)g->N * a.Ho * a.Wo;
   if (mp >= (1ll << 31) || (long long)(a.W + 8) * a.ldx >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
@@ -1120,8 +1132,14 @@ extern "C" int dg_conv3x3_wgrad_f8(const dg_conv_geom* g, const void* xq, const 
   const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
   if (granted < 0) return DG_ERR_LAUNCH;
   if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb);
-  constexpr int lds = 3 * (64 * 128 + 72 * 128);
-  hipLaunchKernelGGL(wg3w_f8_kernel, dim3(ntiles, splits), dim3(256), lds, st, a);
+  if (g->stride == 2) {
+    constexpr int lds2 = 3 * (64 * 128 + 17 * 1152);
+    DG_SET_MAX_LDS_ONCE((&wg3w_f8_kernel<true>), lds2);
+    hipLaunchKernelGGL(wg3w_f8_kernel<true>, dim3(ntiles, splits), dim3(256), lds2, st, a);
+  } else {
+    constexpr int lds = 3 * (64 * 128 + 9 * 1024);
+    hipLaunchKernelGGL(wg3w_f8_kernel<false>, dim3(ntiles, splits), dim3(256), lds, st, a);
+  }
   if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
   return wg_det_end(a, plan, lo, span, st);
 }

@@ -281,10 +281,16 @@ class NativeCritic:
         # producing epilogue writes the copy (dg_epilogue.out_u) beside the MXFP8 one: activation act[l-1] and adjoint us[l] of every
         # eligible layer l, and the penalty's tangents.  Until a role's exponents exist (first pass) its layers use the bf16 kernel.
         ubuf = lambda t: (o.zeros(*t.shape, dtype=torch.uint8), o.zeros(t.shape[-1] // 32, dtype=torch.uint8))
-        self.wg8 = [self.f8 and l > 0 and bool(o.f8_eligible(cv, "wgrad")) and self.actq[l - 1] is not None and self.usq[l] is not None
+        # (not layer 1: its input is the first layer's megapixel activation, whose store-bound im2col kernel would have to write a
+        # third copy -- 4.3 GB per pass at configs[1] -- for a weight gradient that is itself HBM-bound)
+        self.wg8 = [self.f8 and l > 1 and bool(o.f8_eligible(cv, "wgrad")) and self.actq[l - 1] is not None and self.usq[l] is not None
                     for l, cv in enumerate(self.convs)]
         self.actu = [ubuf(self.acts[l]) if l + 1 < 8 and self.wg8[l + 1] else None for l in range(8)]
         self.usu = [ubuf(self.us[l]) if self.wg8[l] else None for l in range(8)]
+        # the adjoints of the loss passes (d out = +-1 / B) and of the penalty pass (d out = 1) differ by the batch size: one exponent
+        # set per kind of pass over the same byte buffers ("loss": usu[l][1], "gp": us_exp_gp[l])
+        self.us_exp_gp = [o.zeros(self.us[l].shape[-1] // 32, dtype=torch.uint8) if self.wg8[l] else None for l in range(8)]
+        self._us_gp_exp_ok = False
         self.tan_exp = [o.zeros(self.acts[l].shape[-1] // 32, dtype=torch.uint8) if l + 1 < 8 and self.wg8[l + 1] else None for l in range(8)]
         self._tanu = None
         self._act_exp_ok = self._us_exp_ok = self._tan_exp_ok = False     # exponents of the role initialised by an earlier pass
@@ -365,7 +371,7 @@ class NativeCritic:
         return self.out
 
     # ---- adjoint chain (backward of a forward just run on x) ---------------------------------------
-    def backward(self, x, dout_value, wgrad=True, dx=None, fc1_slot=None, update_exp=True):
+    def backward(self, x, dout_value, wgrad=True, dx=None, fc1_slot=None, u_role="loss"):
         """d(out_b)/d(.) * dout_value for every sample.  wgrad: accumulate parameter gradients
         (autograd backward of wasserstein.py:52); dx: if given, receives the input gradient
         (wasserstein.py:100-106 / :80).  ``fc1_slot``: FC1's adjoint rows go to that slot and its weight gradient is left
@@ -385,22 +391,26 @@ class NativeCritic:
             o.colsum(uh1, P.grad("classifier.0.bias"))
         o.linear_dx(uh1[:, :FC_HID_P], P.w2d("classifier.0.weight"), self.us[7].view(self.B, self.fc_k),
                     mask=y7, mask_slope=C_SLOPE, o_real=FC_HID, net="C")
+        # fp8 weight gradients: which exponent set this pass's adjoint copies are written with (None: nobody reads them)
+        us_u = self.f8 and ((u_role == "loss" and wgrad and self._us_exp_ok) or (u_role == "gp" and self._us_gp_exp_ok))
+        uexp = (lambda l: self.usu[l][1] if u_role == "loss" else self.us_exp_gp[l])
         if self.usq[7] is not None:       # the only adjoint that does not come out of a conv epilogue
             o.quant_mxfp8(self.us[7], *self.usq[7])
-        us_u = self.f8 and self._us_exp_ok          # this pass's adjoints get (valid) uniform-scale copies
+            if self.usu[7] is not None and us_u:
+                o.quant_uniform(self.us[7], self.usu[7][0], uexp(7))
         for l in range(7, -1, -1):
             cv = self.convs[l]
             name = f"features.{2 * l}.weight"
             xin = self.acts[l - 1] if l > 0 else x
             if wgrad:   # features.0 also carries the only conv bias of the critic (critic.py:21-23)
                 if self.f8 and self.wg8[l] and us_u and self._u_act_live:
-                    o.conv_wgrad_f8(cv, self.actu[l - 1][0], self.actu[l - 1][1], self.usu[l][0], self.usu[l][1], P.grad(name).reshape(-1))
+                    o.conv_wgrad_f8(cv, self.actu[l - 1][0], self.actu[l - 1][1], self.usu[l][0], uexp(l), P.grad(name).reshape(-1))
                 else:
                     o.conv_wgrad(cv, xin, self.us[l], P.grad(name).reshape(-1), db=P.grad("features.0.bias") if l == 0 else None)
             if l > 0:
                 f8kw = dict(xq=self.usq[l], wq=self.wq_d[l], out_q=self.usq[l - 1]) if self.f8 else {}
                 if us_u and self.usu[l - 1] is not None:
-                    f8kw["out_u"] = self.usu[l - 1]
+                    f8kw["out_u"] = (self.usu[l - 1][0], uexp(l - 1))
                 if self.act_bits:
                     o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask_bits=self.act_bits[l - 1], mask_slope=C_SLOPE, **f8kw)
                 else:
@@ -408,23 +418,25 @@ class NativeCritic:
             elif dx is not None:
                 o.conv_dgrad(cv, self.us[0], P.wd(name), dx)
         self._us_live = us_u
-        if self.f8 and update_exp:            # (the penalty pass updates after its tangent weight gradients have read the adjoint copies)
-            self._update_exponents(acts=wgrad)
+        if self.f8 and u_role == "loss" and wgrad:     # (the penalty pass updates after its tangent weight gradients have read the copies)
+            self._update_exponents("loss")
 
-    def _update_exponents(self, acts=True):
-        """After a pass's weight gradients have consumed the uniform-scale copies: the exponents the NEXT pass writes them with =
-        the largest MXFP8 block exponent this pass's tensors reached (+1: values may grow from pass to pass; saturation at +-448
-        beyond that, like the MX rule itself)."""
-        o = self.ops
+    def _update_exponents(self, role):
+        """After a pass's weight gradients have consumed the uniform-scale copies: the exponents the NEXT pass of the same kind writes
+        them with = the largest MXFP8 block exponent this pass's tensors reached (+1: values may grow from pass to pass; saturation
+        at +-448 beyond that, like the MX rule itself).  One launch for all tensors of the pass."""
+        pairs = []
         for l in range(8):
-            if acts and self.actu[l] is not None:
-                o.block_exp_max(self.actq[l][1], self.actu[l][1])
+            if role == "loss" and self.actu[l] is not None:
+                pairs.append((self.actq[l][1], self.actu[l][1]))
             if self.usu[l] is not None:
-                o.block_exp_max(self.usq[l][1], self.usu[l][1])
-        if acts and any(u is not None for u in self.actu):
-            self._act_exp_ok = True
-        if any(u is not None for u in self.usu):
-            self._us_exp_ok = True
+                pairs.append((self.usq[l][1], self.usu[l][1] if role == "loss" else self.us_exp_gp[l]))
+        if pairs:
+            self.ops.block_exp_max_batch(pairs)
+            if role == "loss":
+                self._act_exp_ok = self._us_exp_ok = True
+            else:
+                self._us_gp_exp_ok = True
 
     # ---- gradient penalty: forward, adjoint, norm, tangent forward + weight gradients -------------
     def fc1_flush(self, accumulate=False):
@@ -441,10 +453,10 @@ class NativeCritic:
         the tangent is v0 = dGP/dg pushed forward through the same masked linear maps."""
         o, P = self.ops, self.P
         self.forward(xhat)
-        self.backward(xhat, 1.0, wgrad=False, dx=g_buf, fc1_slot=fc1_slot, update_exp=False)
+        self.backward(xhat, 1.0, wgrad=False, dx=g_buf, fc1_slot=fc1_slot, u_role="gp")
         self.gp_tangent(g_buf, v_buf, ss, coef, gp_scalar, hp, b_global, 0, fc1_slot)
         if self.f8:
-            self._update_exponents(acts=False)
+            self._update_exponents("gp")
 
     def gp_tangent(self, g_buf, v_buf, ss, coef, gp_scalar, hp: HyperParams, b_global, r0, fc1_slot):
         """Second half of the penalty (after g = dC/dx-hat is in ``g_buf``): norm, v0 = dGP/dg, tangent forward and the
@@ -475,7 +487,7 @@ class NativeCritic:
         for l, cv in enumerate(self.convs):
             name = f"features.{2 * l}.weight"
             if self.f8 and self.wg8[l] and tu is not None and getattr(self, "_us_live", False) and r0 == 0:
-                o.conv_wgrad_f8(cv, tu[0], tu[1], self.usu[l][0], self.usu[l][1], P.grad(name).reshape(-1))
+                o.conv_wgrad_f8(cv, tu[0], tu[1], self.usu[l][0], self.us_exp_gp[l], P.grad(name).reshape(-1))
             else:
                 o.conv_wgrad(cv, t, us[l], P.grad(name).reshape(-1))
             if self.f8 and l > 0 and self.tan_exp[l - 1] is not None and tq is not None:

@@ -273,11 +273,11 @@ class HipOps:
 
     def f8_eligible(self, cv: Conv, kind):
         """Does this layer's forward ("fwd") / data gradient ("dgrad") run on the MXFP8 kernel in f8 mode, its weight gradient
-        ("wgrad") on the fp8 kernel with uniform-scale operands (dg_conv3x3_wgrad_f8: stride 1, channel counts that are multiples
-        of 128, rows of a multiple of 64 pixels)?"""
+        ("wgrad") on the fp8 kernel with uniform-scale operands (dg_conv3x3_wgrad_f8: channel counts that are multiples of 128,
+        output rows of a multiple of 64 pixels)?"""
         if kind == "wgrad":
-            return (self.f8 and self.f8_wgrad and cv.net == "C" and cv.stride == 1 and not cv.pixel_shuffle and cv.Cin % 128 == 0
-                    and cv.Cout % 128 == 0 and cv.W % 64 == 0)
+            return (self.f8 and self.f8_wgrad and cv.net == "C" and not cv.pixel_shuffle and cv.Cin % 128 == 0
+                    and cv.Cout % 128 == 0 and cv.Wo % 64 == 0)
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
         nets = ("C", "G") if (self.f8_generator and kind == "fwd") else ("C",)
         return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
@@ -341,16 +341,40 @@ class HipOps:
     def block_exp_max(self, scales, out, margin=1):
         """out[b] (uint8 [C / 32]) = min(254, max over pixels of the MXFP8 scale bytes of block b + margin): the exponents the
         NEXT pass's uniform-scale copy of this tensor is written with (dg_block_exp_max)."""
-        nb = scales.shape[-1]
-        assert scales.dtype == torch.uint8 and out.dtype == torch.uint8 and out.numel() == nb and scales.stride(-1) == 1
-        ld = scales.stride(-2)
-        rows = scales.numel() // nb
-        assert scales.dim() == 2 or all(scales.stride(i) == scales.stride(i + 1) * scales.shape[i + 1] for i in range(scales.dim() - 2)), scales.stride()
+        self.block_exp_max_batch([(scales, out)], margin)
+
+    def block_exp_max_batch(self, pairs, margin=1):
+        """The same for a list of (scales, out) pairs in one launch per 16 tensors (dg_block_exp_max_batch)."""
         if self._exp_scratch is None:
-            self._exp_scratch = torch.zeros(64, dtype=torch.int32, device=self.device)
-        check(self.lib.dg_block_exp_max(_ptr(scales), rows, ld, nb, int(margin), _ptr(out), _ptr(self._exp_scratch), self._stream()), "dg_block_exp_max")
+            self._exp_scratch = torch.zeros(64 * _lib.EXP_BATCH_MAX, dtype=torch.int32, device=self.device)
+        for k in range(0, len(pairs), _lib.EXP_BATCH_MAX):
+            b = _lib.ExpBatch()
+            chunk = pairs[k:k + _lib.EXP_BATCH_MAX]
+            b.n = len(chunk)
+            nbytes = 0
+            for i, (scales, out) in enumerate(chunk):
+                nb = scales.shape[-1]
+                assert scales.dtype == torch.uint8 and out.dtype == torch.uint8 and out.numel() == nb and scales.stride(-1) == 1
+                assert scales.dim() == 2 or all(scales.stride(d) == scales.stride(d + 1) * scales.shape[d + 1] for d in range(scales.dim() - 2)), scales.stride()
+                b.scales[i], b.rows[i], b.ld[i], b.nblocks[i], b.out[i] = scales.data_ptr(), scales.numel() // nb, scales.stride(-2), nb, out.data_ptr()
+                nbytes += scales.numel()
+            check(self._timed("ew_exp_max", 0.0, lambda: self.lib.dg_block_exp_max_batch(
+                C.byref(b), int(margin), _ptr(self._exp_scratch), self._stream()), float(nbytes), "C"), "dg_block_exp_max_batch")
 
     _exp_scratch = None
+
+    def quant_uniform(self, src, q, exps):
+        """q = the uniform-scale E4M3 form of src [..., C] (one exponent per 32-channel block, ``exps`` uint8 [C / 32]): dg_quant_uniform."""
+        Cc = src.shape[-1]
+        assert q.dtype == torch.uint8 and q.shape == src.shape and exps.dtype == torch.uint8 and exps.numel() == Cc // 32
+        if src.dim() == 4:
+            ld, rows = pix_layout(src)
+            ldq = pix_layout(q)[0]
+        else:
+            assert src.dim() == 2
+            ld, rows, ldq = src.stride(0), src.shape[0], q.stride(0)
+        sdt = _lib.DG_F32 if src.dtype == torch.float32 else _lib.DG_BF16
+        check(self.lib.dg_quant_uniform(sdt, _ptr(src), rows, ld, Cc, _ptr(exps), _ptr(q), ldq, self._stream()), "dg_quant_uniform")
 
     def _f8_buf(self, key, shape):
         n = 1
@@ -389,7 +413,7 @@ class HipOps:
     def conv_wgrad_f8(self, cv: Conv, xq, ex, dyq, ey, dw):
         """dw (flat fp32, accumulated into) += weight gradient from E4M3 operands with per-32-channel-block exponents (uint8 tensors
         ``ex`` [Cin / 32], ``ey`` [Cout / 32]; x = xq * 2^(ex - 127)): dg_conv3x3_wgrad_f8.  Raises on shapes the kernel does not
-        take (stride 2, channel counts that are not multiples of 128, rows that are not multiples of 64 pixels)."""
+        take (channel counts that are not multiples of 128, output rows that are not multiples of 64 pixels)."""
         assert xq.dtype == torch.uint8 and dyq.dtype == torch.uint8 and ex.dtype == torch.uint8 and ey.dtype == torch.uint8
         assert dw.dtype == torch.float32 and dw.numel() == cv.Cout * 9 * cv.Cin and ex.numel() == cv.Cin // 32 and ey.numel() == cv.Cout // 32
         g = self._geom(cv, pix_layout(xq)[0], pix_layout(dyq)[0])

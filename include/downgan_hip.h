@@ -347,8 +347,27 @@ typedef struct dg_f8_operands {
 /* out[b] = min(254, max over rows r of scales[r * ld + b] + margin), b < nblocks: the largest MXFP8 block exponent a tensor's
  * 32-channel block b reached anywhere (scales = the E8M0 bytes dg_quant_mxfp8 / dg_epilogue.out_qs wrote) -- the per-block exponent
  * of the uniform-scale copy (dg_epilogue.out_u) of the NEXT pass over the same tensor.  nblocks <= 64, a multiple of 4; `scratch`
- * = 64 dwords of device memory the caller owns, ZERO on entry and left zero (one per stream that calls this concurrently). */
+ * = 64 * DG_EXP_BATCH_MAX dwords of device memory the caller owns, ZERO on entry and left zero (one per stream that calls this
+ * concurrently). */
 int dg_block_exp_max(const void* scales, int64_t rows, int64_t ld, int nblocks, int margin, void* out, void* scratch, void* stream);
+
+/* The same for up to DG_EXP_BATCH_MAX tensors in one launch (the fp8 train step refreshes a dozen exponent tables per critic pass);
+ * scratch = 64 * DG_EXP_BATCH_MAX dwords, zero on entry and left zero. */
+#define DG_EXP_BATCH_MAX 16
+typedef struct dg_exp_batch {
+  const void* scales[DG_EXP_BATCH_MAX];
+  int64_t rows[DG_EXP_BATCH_MAX];
+  int64_t ld[DG_EXP_BATCH_MAX];
+  int nblocks[DG_EXP_BATCH_MAX];
+  void* out[DG_EXP_BATCH_MAX];
+  int n;
+} dg_exp_batch;
+int dg_block_exp_max_batch(const dg_exp_batch* b, int margin, void* scratch, void* stream);
+
+/* Stand-alone form of dg_epilogue.out_u: q[r][c] = E4M3(src[r][c] / 2^(exps[c / 32] - 127)) (saturated at +-448; a block holding a
+ * NaN / Inf becomes 32 x NaN), for tensors that do not come out of a conv epilogue (the critic's last adjoint, written by the FC's
+ * input gradient).  src bf16 / fp32 [rows][ld], C % 128 == 0, q [rows][ldq] bytes. */
+int dg_quant_uniform(int src_dtype, const void* src, int64_t rows, int64_t ld, int C, const void* exps, void* q, int64_t ldq, void* stream);
 
 int dg_quant_mxfp8(int src_dtype, const void* src, int64_t rows, int64_t ld, int C, void* q, int64_t ldq, void* scales,
                    int64_t ldqs, void* stream);   /* ldqs: scale bytes per row, 0 = C/32 */

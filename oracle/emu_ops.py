@@ -175,12 +175,19 @@ class EmuOps:
         scale = torch.ldexp(torch.ones(Cc // 32), exps.reshape(-1).int() - 127).view(1, -1, 1)
         return (q.contiguous().view(torch.float8_e4m3fn).float().reshape(-1, Cc // 32, 32) * scale).reshape(q.shape)
 
+    def quant_uniform(self, src, q, exps):
+        q.copy_(self.uq_quant(src, exps)[0])
+
+    def block_exp_max_batch(self, pairs, margin=1):
+        for scales, out in pairs:
+            self.block_exp_max(scales, out, margin)
+
     def block_exp_max(self, scales, out, margin=1):
         nb = scales.shape[-1]
         out.copy_((scales.reshape(-1, nb).to(torch.int32).amax(0) + int(margin)).clamp(max=254).to(torch.uint8))
 
     def conv_wgrad_f8(self, cv, xq, ex, dyq, ey, dw):
-        assert cv.stride == 1 and cv.Cin % 128 == 0 and cv.Cout % 128 == 0 and cv.W % 64 == 0 and not cv.pixel_shuffle
+        assert cv.Cin % 128 == 0 and cv.Cout % 128 == 0 and cv.Wo % 64 == 0 and not cv.pixel_shuffle
         self.conv_wgrad(cv, self.uq_dequant(xq, ex), self.uq_dequant(dyq, ey), dw)
 
     # ---- MXFP8 (csrc/quant.hip): OCP E4M3 elements, one E8M0 scale per block of 32 consecutive channels (OCP MX layout);
@@ -212,8 +219,8 @@ class EmuOps:
 
     def f8_eligible(self, cv, kind):
         if kind == "wgrad":
-            return (self.f8 and self.f8_wgrad and cv.net == "C" and cv.stride == 1 and not cv.pixel_shuffle and cv.Cin % 128 == 0
-                    and cv.Cout % 128 == 0 and cv.W % 64 == 0)
+            return (self.f8 and self.f8_wgrad and cv.net == "C" and not cv.pixel_shuffle and cv.Cin % 128 == 0
+                    and cv.Cout % 128 == 0 and cv.Wo % 64 == 0)
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
         nets = ("C", "G") if (self.f8_generator and kind == "fwd") else ("C",)
         return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle

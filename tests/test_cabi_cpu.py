@@ -93,7 +93,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pairs = [("dg_epilogue", _lib.Epilogue), ("dg_conv_geom", _lib.ConvGeom), ("dg_gg_desc", _lib.GGDesc),
              ("dg_ssim_params", _lib.SsimParams), ("dg_msssim_combine", _lib.MsssimCombine),
-             ("dg_f8_operands", _lib.F8Operands), ("dg_field_planes", _lib.FieldPlanes), ("dg_finite_bufs", _lib.FiniteBufs)]
+             ("dg_f8_operands", _lib.F8Operands), ("dg_field_planes", _lib.FieldPlanes), ("dg_finite_bufs", _lib.FiniteBufs),
+             ("dg_exp_batch", _lib.ExpBatch)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{root}/include/downgan_hip.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -254,19 +254,20 @@ def _quant_uniform(t, exps):
     return q.view(torch.uint8), q.float() * scale
 
 
-@pytest.mark.parametrize("cfg", [(2, 16, 64, 128, 128), (1, 8, 128, 256, 128), (1, 12, 64, 128, 384), (3, 5, 64, 256, 256)])
+@pytest.mark.parametrize("cfg", [(2, 16, 64, 128, 128, 1), (1, 8, 128, 256, 128, 1), (1, 12, 64, 128, 384, 1), (3, 5, 64, 256, 256, 1),
+                                 (2, 16, 128, 128, 128, 2), (1, 6, 256, 256, 128, 2), (1, 10, 128, 128, 256, 2)])
 def test_wgrad_f8_uniform_scales(cfg):
     """dg_conv3x3_wgrad_f8 (contraction over pixels on v_mfma_scale_f32_32x32x64_f8f6f4; operands E4M3 with one exponent per
     32-channel block of the whole tensor) against the emulation's fp32 weight gradient of the DEQUANTISED operands: products of two
     E4M3 values are exact in fp32, so only the summation order differs (1e-5 of the largest entry).  Accumulates into dw.
     Reference math: autograd of DoWnGAN/networks/critic.py:34-88 (weight gradient of a 3x3 conv, padding 1)."""
     from oracle.emu_ops import EmuOps
-    N, H, W, ci, co = cfg
+    N, H, W, ci, co, st = cfg
     g = torch.Generator().manual_seed(sum(cfg))
     hip, emu = HipOps("bf16"), EmuOps("f32")
-    cv = Conv(N, H, W, ci, co)
+    cv = Conv(N, H, W, ci, co, st)
     x = torch.randn(N, H, W, ci, generator=g) * torch.logspace(-2, 1, ci).view(1, 1, 1, ci)        # channels of very different size
-    dy = torch.randn(N, H, W, co, generator=g) * 0.01
+    dy = torch.randn(N, H // st, W // st, co, generator=g) * 0.01
     # exponents: the block's floor(log2 amax) - 8 + 127 (the OCP MX rule applied to the whole tensor), one block deliberately too small (saturates)
     def exps(t):
         am = t.abs().reshape(-1, t.shape[-1] // 32, 32).amax(dim=(0, 2))
@@ -289,7 +290,7 @@ def test_wgrad_f8_uniform_scales(cfg):
     dw3 = torch.zeros(co * 9 * ci); emu.conv_wgrad(cv, xd, dd, dw3)
     assert float((dw2.cpu() - dw3).abs().max()) <= 1e-5 * float(dw3.abs().max()) * 8, cfg
     # shapes the kernel does not take are refused, not mis-computed
-    for bad in (Conv(N, H, 32, ci, co), Conv(N, H, W, ci, co, 2), Conv(N, H, W, 64, co)):
+    for bad in (Conv(N, H, 32 * st, ci, co, st), Conv(N, H, W, 64, co, st)):
         with pytest.raises((RuntimeError, AssertionError)):
             hip.conv_wgrad_f8(bad, torch.zeros(bad.N, bad.H, bad.W, bad.Cin, dtype=torch.uint8).cuda(), torch.zeros(max(bad.Cin // 32, 1), dtype=torch.uint8).cuda(),
                               torch.zeros(bad.N, bad.Ho, bad.Wo, co, dtype=torch.uint8).cuda(), ey.cuda(), torch.zeros(co * 9 * bad.Cin).cuda())
@@ -354,3 +355,18 @@ def test_block_exp_max_kernel():
             hip.block_exp_max(dev[:, :nb], out, margin=margin)
             assert torch.equal(out.cpu(), (sc[:, :nb].int().amax(0) + margin).to(torch.uint8)), (rows, nb, ld, margin)
         assert int(hip._exp_scratch.abs().sum()) == 0                  # the scratch is left zero
+
+
+def test_quant_uniform_kernel():
+    """dg_quant_uniform == the emulation's uq_quant, bit for bit (bf16 and fp32 sources, a saturating block, a poisoned block)."""
+    from oracle.emu_ops import EmuOps
+    g = torch.Generator().manual_seed(9)
+    hip = HipOps("bf16")
+    for dt in (torch.bfloat16, torch.float32):
+        x = (torch.randn(3, 7, 5, 256, generator=g) * torch.logspace(-3, 1, 256)).to(dt)
+        x[1, 2, 3, 70] = float("nan")
+        exps = torch.tensor([118, 120, 121, 122, 125, 126, 128, 124], dtype=torch.uint8)
+        q = torch.zeros(x.shape, dtype=torch.uint8).cuda()
+        hip.quant_uniform(x.cuda(), q, exps.cuda())
+        ref, _ = EmuOps.uq_quant(x, exps)
+        assert torch.equal(q.cpu(), ref), int((q.cpu() != ref).sum())
