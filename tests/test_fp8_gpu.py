@@ -2,6 +2,9 @@
 forward / stride-2 forward / data-gradient convs of the critic's wide layers (critic.py:25-88) against fp32 convolutions of
 the SAME dequantised operands (products of E4M3 values are exact in fp32, so only accumulation order and the bf16 rounding
 of the result differ), and one critic + generator iteration of the engine in fp8 mode against the emulated engine."""
+import json
+import os
+
 import pytest
 import torch
 
@@ -370,3 +373,28 @@ def test_quant_uniform_kernel():
         hip.quant_uniform(x.cuda(), q, exps.cuda())
         ref, _ = EmuOps.uq_quant(x, exps)
         assert torch.equal(q.cpu(), ref), int((q.cpu() != ref).sum())
+
+
+def test_fp8_weight_gradient_quality_at_cfg2_shapes():
+    """GATE at BASELINE configs[1] shapes (batch 1): the critic's parameter gradients of the first iteration in fp8 mode against the
+    fp32-parity mode, with the bf16 and with the fp8 weight-gradient kernels (tools/fp8_drift.py::first_step_gradients).  At the
+    initial weights the gradient is a nearly cancelling difference of the real and the generated batch's terms, which amplifies every
+    rounding: bf16 is 2-9 % off (cosine >= 0.99), the MXFP8 activations / adjoints 16-39 % (cosine 0.92-0.99; recorded in
+    profiles/fp8_drift_cfg2.json).  The fp8 WEIGHT GRADIENT (uniform-scale E4M3 operands, delayed per-block exponents) may cost at
+    most 0.02 of cosine on top of that on any layer (observed <= 0.013), and no layer may fall below 0.90."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fp8_drift", os.path.join(root, "tools", "fp8_drift.py"))
+    fd = importlib.util.module_from_spec(spec); spec.loader.exec_module(fd)
+    res = fd.first_step_gradients(1, 128, 128, 16)
+    assert res.pop("_layers_on_the_fp8_weight_gradient_kernel") == [False, False, True, True, True, True, True, True]
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "fp8_wgrad_quality_cfg2.json"), "w") as f:
+            json.dump(res, f, indent=1)
+    except OSError:
+        pass
+    for k, v in res.items():
+        assert v["bf16"]["cosine"] >= 0.985, (k, v)
+        assert v["fp8"]["cosine"] >= v["fp8_bf16_wgrad"]["cosine"] - 0.02, (k, v)
+        assert v["fp8"]["cosine"] >= 0.90, (k, v)

@@ -43,11 +43,17 @@ def run(f8, steps, B, S, F_, nrb, fresh_batches):
 
 
 def first_step_gradients(B, S, F_, nrb):
-    """critic parameter gradients of the first critic iteration (no update) in fp32-parity, bf16 and fp8 mode: relative l2
-    error and cosine of the bf16 / fp8 gradient against the fp32 one, per parameter -- the sharp, dynamics-free drift."""
+    """critic parameter gradients of a critic iteration on the initial weights (no update) in fp32-parity, bf16 and fp8 mode:
+    relative l2 error and cosine against the fp32 gradient, per parameter -- the sharp, dynamics-free drift.  fp8 mode twice: with
+    the bf16 weight-gradient kernels (ops.f8_wgrad = False: only the adjoints carry fp8 error) and with the fp8 weight gradients
+    (dg_conv3x3_wgrad_f8) -- taken from the SECOND of two identical iterations, the first one being the pass that initialises the
+    per-block exponents (no update in between: the same gradient in exact arithmetic)."""
     grads = {}
-    for mode in ("f32", "bf16", "fp8"):
-        ops = HipOps("f32" if mode == "f32" else "bf16", "cuda:0", f8_critic=mode == "fp8", f8_generator=mode == "fp8")
+    for mode in ("f32", "bf16", "fp8_bf16_wgrad", "fp8"):
+        f8 = mode.startswith("fp8")
+        ops = HipOps("f32" if mode == "f32" else "bf16", "cuda:0", f8_critic=f8, f8_generator=f8)
+        if mode == "fp8_bf16_wgrad":
+            ops.f8_wgrad = False
         eng = TrainEngine(ops, S, F_, 2, B, HyperParams(batch_size=B), num_res_blocks=nrb)
         eng.G.load_state_dict(synthetic.generator_params(F_, 2, 2, nrb))
         eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
@@ -55,16 +61,19 @@ def first_step_gradients(B, S, F_, nrb):
         xc, xf = ops.zeros(B, S, S, 16), ops.zeros(B, 8 * S, 8 * S, 16)
         ops.nchw_to_nhwc(torch.from_numpy(coarse).cuda(), xc)
         ops.nchw_to_nhwc(torch.from_numpy(fine).cuda(), xf)
-        eng.critic_iteration(xc, xf, torch.from_numpy(synthetic.alpha(B, 0)).cuda(), apply_update=False)
+        for _ in range(2 if mode == "fp8" else 1):
+            eng.critic_iteration(xc, xf, torch.from_numpy(synthetic.alpha(B, 0)).cuda(), apply_update=False)
+        if mode == "fp8":
+            grads["_fp8_layers"] = [bool(w) for w in eng.C.wg8]
         grads[mode] = {k: v.double() for k, v in eng.C.grad_dict().items()}
         del eng
         torch.cuda.empty_cache()
-    out = {}
+    out = {"_layers_on_the_fp8_weight_gradient_kernel": grads.pop("_fp8_layers")}
     for k, g in grads["f32"].items():
         if float(g.norm()) == 0:
             continue
         out[k] = {m: {"rel_l2": float((grads[m][k] - g).norm() / g.norm()),
-                      "cosine": float((grads[m][k] * g).sum() / (grads[m][k].norm() * g.norm() + 1e-300))} for m in ("bf16", "fp8")}
+                      "cosine": float((grads[m][k] * g).sum() / (grads[m][k].norm() * g.norm() + 1e-300))} for m in ("bf16", "fp8_bf16_wgrad", "fp8")}
     return out
 
 
@@ -76,8 +85,21 @@ def main():
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--rrdbs", type=int, default=16)
     ap.add_argument("--fresh-batches", action="store_true", help="a new synthetic batch every step instead of one fixed batch")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "fp8_drift_cfg2.json"))
+    ap.add_argument("--gradients-only", action="store_true", help="only the first-step gradient comparison (2 minutes instead of 10)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fp8_drift_cfg2.json"))
     a = ap.parse_args()
+    if a.gradients_only:
+        res = {"first_step_critic_gradients_vs_fp32": first_step_gradients(min(a.batch, 2), a.coarse, a.filters, a.rrdbs)}
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+        for k, v in res["first_step_critic_gradients_vs_fp32"].items():
+            if k.startswith("_"):
+                print(k, v)
+                continue
+            print(f"{k:24s} bf16 rel {v['bf16']['rel_l2']:.3f} cos {v['bf16']['cosine']:.4f} | fp8, bf16 wgrad rel {v['fp8_bf16_wgrad']['rel_l2']:.3f} "
+                  f"cos {v['fp8_bf16_wgrad']['cosine']:.4f} | fp8 rel {v['fp8']['rel_l2']:.3f} cos {v['fp8']['cosine']:.4f}")
+        return
     ref = run(False, a.steps, a.batch, a.coarse, a.filters, a.rrdbs, a.fresh_batches)
     f8 = run("all", a.steps, a.batch, a.coarse, a.filters, a.rrdbs, a.fresh_batches)
     f8c = run("critic", a.steps, a.batch, a.coarse, a.filters, a.rrdbs, a.fresh_batches)
@@ -109,7 +131,11 @@ def main():
         print(st["step"], {k: (round(st[k]["bf16"], 5), round(st[k]["fp8"], 5)) for k in ("critic_loss", "gp_ret", "w_estimate") if k in st})
     print("max rel:", {k: f"{v:.3g}" for k, v in res["max_rel"].items()})
     for k, v in res["first_step_critic_gradients_vs_fp32"].items():
-        print(f"{k:24s} bf16 rel {v['bf16']['rel_l2']:.3f} cos {v['bf16']['cosine']:.4f} | fp8 rel {v['fp8']['rel_l2']:.3f} cos {v['fp8']['cosine']:.4f}")
+        if k.startswith("_"):
+            print(k, v)
+            continue
+        print(f"{k:24s} bf16 rel {v['bf16']['rel_l2']:.3f} cos {v['bf16']['cosine']:.4f} | fp8, bf16 wgrad rel {v['fp8_bf16_wgrad']['rel_l2']:.3f} "
+              f"cos {v['fp8_bf16_wgrad']['cosine']:.4f} | fp8 rel {v['fp8']['rel_l2']:.3f} cos {v['fp8']['cosine']:.4f}")
 
 
 if __name__ == "__main__":
