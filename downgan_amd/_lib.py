@@ -22,7 +22,7 @@ class Epilogue(C.Structure):
                 ("mask", C.c_void_p), ("ldmask", C.c_int64), ("mask_slope", C.c_float),
                 ("accumulate", C.c_int), ("mask_bits", C.c_void_p), ("out_bits", C.c_void_p),
                 ("mask_c0", C.c_int), ("mask_last", C.c_int), ("out_q", C.c_void_p), ("out_qs", C.c_void_p), ("ldqs", C.c_int64),
-                ("out_u", C.c_void_p), ("out_ue", C.c_void_p)]
+                ("out_u", C.c_void_p), ("out_ue", C.c_void_p), ("skip_y", C.c_int)]
 
 
 class ConvGeom(C.Structure):

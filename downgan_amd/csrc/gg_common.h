@@ -43,6 +43,7 @@ struct GGArgs {
   const void* mask_bits; void* out_bits;     // 1-bit LeakyReLU masks (u16 per lane: 4 fragments x 4 channels), see dg_epilogue
   void* out_q; void* out_qs;                 // MXFP8 copy of the stored output (dg_epilogue.out_q / out_qs)
   void* out_u; const unsigned char* out_ue;  // uniform-scale E4M3 copy for the fp8 weight gradient (dg_epilogue.out_u / out_ue)
+  int no_y;                                  // dg_epilogue.skip_y: the bf16 output itself is not stored (only its fp8 copies / mask bits are read)
   int ldqs, qs_shift;                        // scale bytes per pixel of out_qs; log2(Nout / 16) when that stride is not Nout / 32
   long long ldx, ldw, ldy, ldr1, ldr2, ldmask;
   int M, Hg, Wg, Hs, Ws;
@@ -241,7 +242,7 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
       for (int e = 0; e < CPU; ++e) ob |= (vu[e] > 0.f ? 1u : 0u) << (u * CPU + e);
     }
     pk[u] = IO::pack(vu);
-    __builtin_amdgcn_raw_buffer_store_b128(pk[u], R.rY, offy, u * 16, 0);
+    if (F >= 0 ? !(F & 4096) : !a.no_y) __builtin_amdgcn_raw_buffer_store_b128(pk[u], R.rY, offy, u * 16, 0);
   }
   if (F >= 0 && (F & 1024)) *ob_ret = ob;      // the caller stores the word itself (gg_im2col_direct_kernel: two words per store)
   else if (F >= 0) { if (f_ob) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, boff, 0, 0); }
@@ -535,7 +536,7 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
   // the flag combinations the train step launches most get straight-line instances; everything else the general one.
   // Decoded per 64-channel half: the activation mask may start at channel mask_c0 (a multiple of 64 here, else general path)
   const int key0 = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.r1 ? 8 : 0) | (a.r2 ? 16 : 0) | (a.accumulate ? 64 : 0) |
-                   (a.out_q ? 256 : 0) | (a.out_u ? 2048 : 0);
+                   (a.out_q ? 256 : 0) | (a.out_u ? 2048 : 0) | (a.no_y ? 4096 : 0);
   auto dispatch = [&](auto htag) {
     constexpr int h = decltype(htag)::value;
     int key = key0;
@@ -558,6 +559,10 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       case 261: run(std::integral_constant<int, 261>{}, htag); break;  // fp8 mode: LeakyReLU + out_bits + MXFP8 copy (critic forward)
       case 2306: run(std::integral_constant<int, 2306>{}, htag); break; // ... + the uniform-scale copy for the fp8 weight gradient (258 + 2048)
       case 2309: run(std::integral_constant<int, 2309>{}, htag); break; // (261 + 2048)
+      case 4354: run(std::integral_constant<int, 4354>{}, htag); break; // 258 / 261 / 2306 / 2309 without the bf16 store (+ 4096: dg_epilogue.skip_y)
+      case 4357: run(std::integral_constant<int, 4357>{}, htag); break;
+      case 6402: run(std::integral_constant<int, 6402>{}, htag); break;
+      case 6405: run(std::integral_constant<int, 6405>{}, htag); break;
       default: run(std::integral_constant<int, -1>{}, htag); break;
     }
   };

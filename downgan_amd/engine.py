@@ -293,6 +293,7 @@ class NativeCritic:
         self._us_gp_exp_ok = False
         self.tan_exp = [o.zeros(self.acts[l].shape[-1] // 32, dtype=torch.uint8) if l + 1 < 8 and self.wg8[l + 1] else None for l in range(8)]
         self._tanu = None
+        self.skip_dead = os.environ.get("DG_F8_KEEP_BF16") is None      # do not store bf16 tensors that only fp8 readers follow (dg_epilogue.skip_y)
         self._act_exp_ok = self._us_exp_ok = self._tan_exp_ok = False     # exponents of the role initialised by an earlier pass
         self._u_act_live = False                                          # this pass's forward wrote valid uniform-scale activations
 
@@ -357,6 +358,11 @@ class NativeCritic:
             f8kw = dict(xq=self.actq[l - 1] if l else None, wq=self.wq_f[l], out_q=self.actq[l]) if self.f8 else {}
             if want_u and self.actu[l] is not None:
                 f8kw["out_u"] = self.actu[l]
+            # the bf16 activation itself is dead when the next conv reads the MXFP8 copy, the masks are bits and the only other
+            # reader -- layer l + 1's weight gradient -- is the fp8 kernel (or does not run in this pass): not stored then
+            if self.f8 and self.skip_dead and 1 <= l <= 6 and self.actq[l] is not None and self.act_bits is not None and o.f8_eligible(cv, "fwd") \
+                    and (not for_wgrad or (want_u and self.wg8[l + 1] and self._us_exp_ok)):
+                f8kw["skip_y"] = True
             o.conv_fwd(cv, cur, P.w(f"features.{2 * l}.weight"), self.acts[l],
                        bias=P.master("features.0.bias") if l == 0 else None, act=C_SLOPE,
                        out_bits=self.act_bits[l] if self.act_bits else None, **f8kw)
@@ -411,6 +417,15 @@ class NativeCritic:
                 f8kw = dict(xq=self.usq[l], wq=self.wq_d[l], out_q=self.usq[l - 1]) if self.f8 else {}
                 if us_u and self.usu[l - 1] is not None:
                     f8kw["out_u"] = (self.usu[l - 1][0], uexp(l - 1))
+                # bf16 adjoint us[l-1]: read only by layer l-1's weight gradient (the next data gradient reads the MXFP8 copy) -- dead when
+                # that is the fp8 kernel, or no weight gradient of this pass's adjoints runs at all (generator iteration)
+                if self.f8 and self.skip_dead and l - 1 >= 1 and self.usq[l - 1] is not None and self.act_bits and o.f8_eligible(cv, "dgrad"):
+                    if u_role == "loss":
+                        dead = (not wgrad) or (self.wg8[l - 1] and us_u and self._u_act_live)
+                    else:       # penalty pass: the tangent weight gradients read the adjoints
+                        dead = self.wg8[l - 1] and us_u and self._tan_exp_ok
+                    if dead:
+                        f8kw["skip_y"] = True
                 if self.act_bits:
                     o.conv_dgrad(cv, self.us[l], P.wd(name), self.us[l - 1], mask_bits=self.act_bits[l - 1], mask_slope=C_SLOPE, **f8kw)
                 else:
@@ -505,6 +520,8 @@ class NativeCritic:
             if self.f8 and self.tan_exp[l] is not None and tqn is not None and self._tan_exp_ok:
                 tun = (self._tanu[l & 1][:self.acts[l].numel()].view(self.acts[l].shape), self.tan_exp[l])
                 f8kw["out_u"] = tun
+                if self.skip_dead and bits and l < 7 and self.wg8[l + 1] and getattr(self, "_us_live", False) and o.f8_eligible(cv, "fwd"):
+                    f8kw["skip_y"] = True        # the bf16 tangent: read by the next conv (MXFP8 copy) and layer l + 1's fp8 weight gradient only
             if bits:
                 o.conv_fwd(cv, t, P.w(name), tn, mask_bits=bits[l], mask_slope=C_SLOPE, **f8kw)
             else:

@@ -221,7 +221,7 @@ class HipOps:
         return (N, H, W, Cc // 64, 4)
 
     def _epilogue(self, out, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None, mask_slope=1.0,
-                  accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None):
+                  accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None, skip_y=False):
         ep = Epilogue()
         ep.bias = bias.data_ptr() if bias is not None else None
         if bias is not None:
@@ -263,6 +263,9 @@ class HipOps:
             assert out_q is not None and u.dtype == torch.uint8 and u.shape == out.shape and u.stride() == out.stride()
             assert ue.dtype == torch.uint8 and ue.is_contiguous() and ue.numel() == out.shape[-1] // 32
             ep.out_u, ep.out_ue = u.data_ptr(), ue.data_ptr()
+        if skip_y:                  # the bf16 output is not stored: only its fp8 copies / mask bits (nobody reads the tensor itself)
+            assert out_q is not None and not accumulate
+            ep.skip_y = 1
         return ep
 
     # ------------------------------------------------------------------ conv family

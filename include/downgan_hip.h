@@ -81,6 +81,9 @@ typedef struct dg_epilogue {
    * derives them from an earlier pass, dg_block_exp_max).  Needs out_q (the copy is formed from the same rounded values). */
   void* out_u;
   const void* out_ue;
+  /* != 0: the output tensor y itself is NOT stored -- only its fp8 copies (out_q required) / mask bits are, for launches whose bf16
+   * result nobody reads (fp8 mode: the next conv reads out_q, the weight gradient out_u, the masks out_bits).  Not with accumulate. */
+  int skip_y;
 } dg_epilogue;
 
 /* Geometry of ONE reference nn.Conv2d(Cin, Cout, kernel_size=3, stride, padding=1) layer

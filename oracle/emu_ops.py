@@ -85,7 +85,10 @@ class EmuOps:
         return torch.stack([(w[..., blk[c], g[c]] >> int(b[c])) & 1 for c in range(Cc)], dim=-1).bool()
 
     def _gather_gemm(self, d, x, w, y, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None,
-                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None):
+                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None, skip_y=False):
+        if skip_y:      # dg_epilogue.skip_y: the fp8 copies / mask bits are formed from the values the launch WOULD store; y keeps its content
+            assert out_q is not None and not accumulate
+            y = y.clone()
         N = d.N
         xs = x.float()
         if d.src_ps:
@@ -258,6 +261,8 @@ class EmuOps:
         if self.f8_eligible(cv, "dgrad"):
             dy = self._f8_operand(dy, xq)
             w_dgrad = self._f8_operand(w_dgrad.view(cv.Cin * 9, cv.Cout), wq)
+        if ep.get("skip_y"):      # the parity classes of a stride-2 layer complete ONE would-be tensor: its copies come from all of them
+            dx, ep = dx.clone(), dict(ep, skip_y=False)
         for d in self._plan(cv, 1, pix_layout(dx)[0], pix_layout(dy)[0]):
             self._gather_gemm(d, dy, w_dgrad, dx, **ep)
 
