@@ -119,9 +119,8 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     a.out_q = ep->out_q; a.out_qs = ep->out_qs;
     a.out_u = ep->out_u; a.out_ue = (const unsigned char*)ep->out_ue;
     if ((a.out_u != nullptr) != (a.out_ue != nullptr) || (a.out_u && !a.out_q)) return DG_ERR_BAD_ARG;
-    if (a.out_u && im2col_small) return DG_ERR_BAD_SHAPE;      // (the first-layer kernels write the MXFP8 copy only)
     a.no_y = ep->skip_y ? 1 : 0;
-    if (a.no_y && (!a.out_q || a.accumulate || im2col_small)) return DG_ERR_BAD_ARG;
+    if (a.no_y && (!a.out_q || a.accumulate)) return DG_ERR_BAD_ARG;          // (the first-layer launcher checks its own shapes)
     // the MXFP8 copy is written by the 64-channel wave-tile epilogues of bf16 launches: same shape rules as the bit masks
     if ((a.out_q != nullptr) != (a.out_qs != nullptr)) return DG_ERR_BAD_ARG;
     if (a.out_q && (d->dtype != DG_BF16 || d->Nout < 128 || d->Nout % 64 || d->dst_ps)) return DG_ERR_BAD_SHAPE;

@@ -384,6 +384,11 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
   const int ob_src = (l15 + 32 * (g & 1)) * 4, ob_sh = 16 * (g >> 1);
   const unsigned ob_off = (unsigned)((l15 * ldb + (c0 >> 6) * 4 + 2 * g) * 2);
   const float zero16[16] = {};
+  float inv_u[2] = {0.f, 0.f};              // uniform-scale copy (dg_epilogue.out_u): 2^(127 - exponent of this lane's 32-channel block)
+  if (F & 2048) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) inv_u[h] = mx_inv_scale((int)a.out_ue[(c0 + 64 * h + 16 * g) >> 5]);
+  }
   auto gather = [&](int grp) -> unsigned {
     const bool live = grp >= 0;
     const unsigned m0 = live ? (unsigned)grp * 16u : 0u;
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
     R.r1 = R.r2 = R.rm = R.rY;
     R.rbi = (F & 2) ? rsrc(a.mask_bits, ldb, 2) : R.rY; R.rbo = (F & 4) ? rsrc(a.out_bits, ldb, 2) : R.rY;
     R.rq = (F & 256) ? rsrc(a.out_q, a.ldy, 1) : R.rY; R.rqs = (F & 256) ? rsrc(a.out_qs, a.ldqs, 1) : R.rY;
+    R.ru = (F & 2048) ? rsrc(a.out_u, a.ldy, 1) : R.rY;
     R.ldy = (int)a.ldy; R.ld1 = R.ld2 = R.ldm = 0;
     unsigned mb[2] = {0u, 0u};
     if (F & 2) {                                                   // both mask words before the first store
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
         Mma<T>::run(fa[4 * h + j], fb, acc[j]);
       }
       epi64_pixel<T, true, F | 512 | ((F & 4) ? 1024 : 0)>(a, R, acc[0], acc[1], acc[2], acc[3], zero16, offy[h], 0u, 0u, 0u, boff[h], mb[h],
-                                                            false, &ob[h]);
+                                                            false, &ob[h], inv_u[h]);
     }
     if (F & 4) {
       const int both = (int)(ob[0] | (ob[1] << 16));
@@ -469,9 +475,11 @@ static int gg_launch_im2col_t(GGArgs& a, hipStream_t st) {
   const bool lean = !a.r1 && !a.r2 && !a.mask && !a.accumulate;
   if constexpr (sizeof(T) == 2) {
     static const bool no_direct = getenv("DG_GG_NOIM2COLDIRECT") != nullptr;
-    const int F = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.out_q ? 256 : 0);
+    const int F = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.out_q ? 256 : 0) | (a.out_u ? 2048 : 0) | (a.no_y ? 4096 : 0);
+    const bool f_ok = F == 0 || F == 1 || F == 2 || F == 5 || F == 258 || F == 261 || F == 2306 || F == 2309 || F == 4354 || F == 4357 || F == 6402 || F == 6405;
+    if ((a.out_u || a.no_y) && !(f_ok && !no_direct && lean && a.Wg % 16 == 0 && a.Nout % 128 == 0 && a.Hs == a.Hg && a.Ws == a.Wg)) return DG_ERR_BAD_SHAPE;
     if (!no_direct && lean && a.Wg % 16 == 0 && a.Nout % 128 == 0 && a.Hs == a.Hg && a.Ws == a.Wg &&
-        (long long)a.M * a.ldy * 2 < (1ll << 46) && (F == 0 || F == 1 || F == 2 || F == 5 || F == 258 || F == 261)) {
+        (long long)a.M * a.ldy * 2 < (1ll << 46) && f_ok) {
       const int ngroups = a.M / 16;
       int nb = a.Hg % 16 == 0 ? ngroups / 16 : (ngroups + 3) / 4;   // tiles of 16 groups / workgroups of 4 groups
       if (nb > 1024) nb = 1024;                                    // 4 workgroups per CU resident, one round
@@ -484,7 +492,13 @@ static int gg_launch_im2col_t(GGArgs& a, hipStream_t st) {
         case 2: hipLaunchKernelGGL((gg_im2col_direct_kernel<2>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
         case 5: hipLaunchKernelGGL((gg_im2col_direct_kernel<5>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
         case 258: hipLaunchKernelGGL((gg_im2col_direct_kernel<258>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
-        default: hipLaunchKernelGGL((gg_im2col_direct_kernel<261>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 261: hipLaunchKernelGGL((gg_im2col_direct_kernel<261>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 2306: hipLaunchKernelGGL((gg_im2col_direct_kernel<2306>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 2309: hipLaunchKernelGGL((gg_im2col_direct_kernel<2309>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 4354: hipLaunchKernelGGL((gg_im2col_direct_kernel<4354>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 4357: hipLaunchKernelGGL((gg_im2col_direct_kernel<4357>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 6402: hipLaunchKernelGGL((gg_im2col_direct_kernel<6402>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        default: hipLaunchKernelGGL((gg_im2col_direct_kernel<6405>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
       }
       return dg_check_launch();
     }

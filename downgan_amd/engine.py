@@ -281,10 +281,11 @@ class NativeCritic:
         # producing epilogue writes the copy (dg_epilogue.out_u) beside the MXFP8 one: activation act[l-1] and adjoint us[l] of every
         # eligible layer l, and the penalty's tangents.  Until a role's exponents exist (first pass) its layers use the bf16 kernel.
         ubuf = lambda t: (o.zeros(*t.shape, dtype=torch.uint8), o.zeros(t.shape[-1] // 32, dtype=torch.uint8))
-        # (not layer 1: its input is the first layer's megapixel activation, whose store-bound im2col kernel would have to write a
-        # third copy -- 4.3 GB per pass at configs[1] -- for a weight gradient that is itself HBM-bound)
-        self.wg8 = [self.f8 and l > 1 and bool(o.f8_eligible(cv, "wgrad")) and self.actq[l - 1] is not None and self.usq[l] is not None
-                    for l, cv in enumerate(self.convs)]
+        # (layer 1 reads the first layer's megapixel activation: its im2col kernel writes the copies too -- and, once the weight gradient
+        # is the fp8 kernel, no longer the 8.6-GB bf16 tensor itself: -7 ms per step at configs[1])
+        self._l0_f8_out = bool(self.convs[0].cin_real) and self.convs[0].W % 16 == 0 and self.convs[0].Cout % 128 == 0
+        self.wg8 = [self.f8 and l > 0 and (l > 1 or self._l0_f8_out) and bool(o.f8_eligible(cv, "wgrad")) and self.actq[l - 1] is not None
+                    and self.usq[l] is not None for l, cv in enumerate(self.convs)]
         self.actu = [ubuf(self.acts[l]) if l + 1 < 8 and self.wg8[l + 1] else None for l in range(8)]
         self.usu = [ubuf(self.us[l]) if self.wg8[l] else None for l in range(8)]
         # the adjoints of the loss passes (d out = +-1 / B) and of the penalty pass (d out = 1) differ by the batch size: one exponent
@@ -360,7 +361,8 @@ class NativeCritic:
                 f8kw["out_u"] = self.actu[l]
             # the bf16 activation itself is dead when the next conv reads the MXFP8 copy, the masks are bits and the only other
             # reader -- layer l + 1's weight gradient -- is the fp8 kernel (or does not run in this pass): not stored then
-            if self.f8 and self.skip_dead and 1 <= l <= 6 and self.actq[l] is not None and self.act_bits is not None and o.f8_eligible(cv, "fwd") \
+            if self.f8 and self.skip_dead and l <= 6 and self.actq[l] is not None and self.act_bits is not None \
+                    and (o.f8_eligible(cv, "fwd") or (l == 0 and self._l0_f8_out)) \
                     and (not for_wgrad or (want_u and self.wg8[l + 1] and self._us_exp_ok)):
                 f8kw["skip_y"] = True
             o.conv_fwd(cv, cur, P.w(f"features.{2 * l}.weight"), self.acts[l],
@@ -520,7 +522,8 @@ class NativeCritic:
             if self.f8 and self.tan_exp[l] is not None and tqn is not None and self._tan_exp_ok:
                 tun = (self._tanu[l & 1][:self.acts[l].numel()].view(self.acts[l].shape), self.tan_exp[l])
                 f8kw["out_u"] = tun
-                if self.skip_dead and bits and l < 7 and self.wg8[l + 1] and getattr(self, "_us_live", False) and o.f8_eligible(cv, "fwd"):
+                if self.skip_dead and bits and l < 7 and self.wg8[l + 1] and getattr(self, "_us_live", False) \
+                        and (o.f8_eligible(cv, "fwd") or (l == 0 and self._l0_f8_out)):
                     f8kw["skip_y"] = True        # the bf16 tangent: read by the next conv (MXFP8 copy) and layer l + 1's fp8 weight gradient only
             if bits:
                 o.conv_fwd(cv, t, P.w(name), tn, mask_bits=bits[l], mask_slope=C_SLOPE, **f8kw)

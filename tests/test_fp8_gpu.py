@@ -388,7 +388,7 @@ def test_fp8_weight_gradient_quality_at_cfg2_shapes():
     spec = importlib.util.spec_from_file_location("fp8_drift", os.path.join(root, "tools", "fp8_drift.py"))
     fd = importlib.util.module_from_spec(spec); spec.loader.exec_module(fd)
     res = fd.first_step_gradients(2, 128, 128, 16)
-    assert res.pop("_layers_on_the_fp8_weight_gradient_kernel") == [False, False, True, True, True, True, True, True]
+    assert res.pop("_layers_on_the_fp8_weight_gradient_kernel") == [False, True, True, True, True, True, True, True]
     try:
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "fp8_wgrad_quality_cfg2.json"), "w") as f:
