@@ -1,10 +1,10 @@
-# rocprofv3 evidence for the default bench command (run ON the GPU box: gpurun -- 'bash tools/prof_r03.sh [tag]'):
+# rocprofv3 evidence for the default bench command (run ON the GPU box: gpurun -- 'bash tools/prof_r04.sh [tag]'):
 #   1. separate FETCH_SIZE / WRITE_SIZE PMC passes -> per-kernel HBM traffic, stamped with the sha256 of the library in use
 #      (written to profiles/ of the box's copy too, so that step 3 reports roofline.traffic from THIS build),
 #   2. kernel-trace stats of the same command,
 #   3. the default bench line (with the CPU baseline, the event-free region and the fp8 mode) and the per-layer tables.
 # Only the small summaries are kept (gpurun_out/<tag>_keep/); copy them into profiles/ afterwards.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
