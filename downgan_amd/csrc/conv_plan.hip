@@ -60,8 +60,7 @@ static int gg_launch(GGArgs& a, int dtype, int N, hipStream_t st) {
     GGArgs b = a;
     if (gg_regroup_taps_by_plane(b)) {
       // >= 256 output channels (bf16): eight waves share one parity-plane patch between two 128-channel halves
-      static const bool no8w = getenv("DG_GG_NO8W") != nullptr;
-      return gg_launch_halo(b, dtype, N, true, false, (dtype == DG_BF16 && !no8w && b.Nout % 256 == 0) ? 8 : 4, st);
+      return gg_launch_halo(b, dtype, N, true, false, (dtype == DG_BF16 && b.Nout % 256 == 0) ? 8 : 4, st);
     }
   }
   if (a.Nout <= 16 && a.sy_mul == 1 && a.sx_mul == 1 && !a.src_ps && !a.dst_ps && a.cch % 8 == 0 && a.Hg >= 8 &&
@@ -77,8 +76,7 @@ static int gg_launch_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st) {
   if (a.sy_mul == 2 && a.sx_mul == 2 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1) {
     GGArgs b = a;
     if (gg_regroup_taps_by_plane(b)) {
-      static const bool no8w = getenv("DG_GG_NO8W") != nullptr;
-      return gg_launch_halo_f8(b, f, N, true, (!no8w && b.Nout % 256 == 0) ? 8 : 4, st);
+      return gg_launch_halo_f8(b, f, N, true, b.Nout % 256 == 0 ? 8 : 4, st);
     }
   }
   return DG_ERR_BAD_SHAPE;
@@ -140,9 +138,8 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
   if (seg) {
     // class order of the merged stride-2 data-gradient launch (conv_halo.hip): classes interleaved per row of tiles while the nine
     // weight taps of the layer fit an XCD's L2 beside everything else (<= 2 MB: the 128- and 256-channel layers, +3-4 %), else one
-    // class per image at a time (512 / 1024 channels: interleaved classes stream four tap sets at once, -2 %).  DG_SEG_ORDER=1|2 forces one.
-    static const int seg_order = getenv("DG_SEG_ORDER") ? atoi(getenv("DG_SEG_ORDER")) : 0;
-    if (seg_order == 2 || (seg_order == 0 && (long long)d->Cred * d->Nout * 18 <= (2ll << 20))) a.seg = 2;
+    // class per image at a time (512 / 1024 channels: interleaved classes stream four tap sets at once, -2 %).
+    if ((long long)d->Cred * d->Nout * 18 <= (2ll << 20)) a.seg = 2;
   }
   if (f8) {
     F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws, f8->ldxs > 0 ? (int)f8->ldxs : d->Cred / 32};
@@ -231,9 +228,8 @@ extern "C" int dg_conv3x3_fwd(const dg_conv_geom* g, const dg_epilogue* ep, cons
 // (conv_halo.hip, SEG): the classes' taps concatenated in class order (1 / 2 / 2 / 4); the destination offset is the workgroup's
 // class parity.  Any epilogue; whole 64-channel reduction blocks (8 chunks), > 64 outputs, tiles of >= 8 x 8.
 static bool seg_dgrad_desc(const dg_gg_desc* d, int n, dg_gg_desc* out) {
-  static const bool off = getenv("DG_GG_NOSEG") != nullptr;
   const int epc = d[0].dtype == DG_F32 ? 4 : 8;
-  if (off || n != 4 || d[0].src_ps || d[0].dst_ps || (d[0].Cred / epc) % 8 || d[0].Nout <= 64 || d[0].Hg < 8 || d[0].Wg < 8) return false;
+  if (n != 4 || d[0].src_ps || d[0].dst_ps || (d[0].Cred / epc) % 8 || d[0].Nout <= 64 || d[0].Hg < 8 || d[0].Wg < 8) return false;
   if (d[0].ntaps != 1 || d[1].ntaps != 2 || d[2].ntaps != 2 || d[3].ntaps != 4) return false;
   if (!gg_halo_row_step_ok(d[0].Ws, d[0].lds, d[0].dtype, 1)) return false;     // oversized rows: four launches on the row-tiled kernel
   *out = d[3];

@@ -277,8 +277,7 @@ static int gg_launch_t(GGArgs& a, hipStream_t st) {
   a.nct = (unsigned)((a.Nout + BC - 1) / BC);
   const unsigned npt = (unsigned)((a.M + BP - 1) / BP);
   a.nwg = a.nct * npt;
-  static const bool force_generic = getenv("DG_GG_GENERIC") != nullptr;
-  const bool fast_ok = a.cch % 8 == 0 && (!a.src_ps || a.cps_src_chunks % 8 == 0) && !force_generic;
+  const bool fast_ok = a.cch % 8 == 0 && (!a.src_ps || a.cps_src_chunks % 8 == 0);
   g_last_kinds |= fast_ok ? 2 : 1;
   if (fast_ok)
     hipLaunchKernelGGL((gg_fast_kernel<T, BP, BC, WP, WC>), dim3(a.nwg), dim3(256), 0, st, a);

@@ -474,7 +474,7 @@ static int gg_launch_im2col_t(GGArgs& a, hipStream_t st) {
   // left 16384 workgroups on 768 slots: 21.3 rounds, the last a third full; +2 % at 1024^2)
   const bool lean = !a.r1 && !a.r2 && !a.mask && !a.accumulate;
   if constexpr (sizeof(T) == 2) {
-    static const bool no_direct = getenv("DG_GG_NOIM2COLDIRECT") != nullptr;
+    constexpr bool no_direct = false;
     const int F = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.out_q ? 256 : 0) | (a.out_u ? 2048 : 0) | (a.no_y ? 4096 : 0);
     const bool f_ok = F == 0 || F == 1 || F == 2 || F == 5 || F == 258 || F == 261 || F == 2306 || F == 2309 || F == 4354 || F == 4357 || F == 6402 || F == 6405;
     if ((a.out_u || a.no_y) && !(f_ok && !no_direct && lean && a.Wg % 16 == 0 && a.Nout % 128 == 0 && a.Hs == a.Hg && a.Ws == a.Wg)) return DG_ERR_BAD_SHAPE;

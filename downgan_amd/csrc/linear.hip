@@ -316,8 +316,7 @@ extern "C" int dg_linear_dx(int dtype, int out_dtype, const float* dy, int ldo, 
   if (B <= 0 || O <= 0 || O > 128 || K <= 0 || K % 8 || ldw % 8 || lddx % 8) return DG_ERR_BAD_SHAPE;
   if (mask && ldmask % 8) return DG_ERR_BAD_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static const bool no_wide = getenv("DG_LIN_NODXWIDE") != nullptr;
-  if (!no_wide && K >= 4096 && (long long)K * 4 < (1ll << 32) && B >= 16) {        // the FC1-sized products: 32 rows per pass, packed FMAs
+  if (K >= 4096 && (long long)K * 4 < (1ll << 32) && B >= 16) {        // the FC1-sized products: 32 rows per pass, packed FMAs
     dim3 gridw((unsigned)((K / 4 + 255) / 256), (unsigned)((B + 31) / 32));
     if (dtype == DG_F32 && out_dtype == DG_F32) {
       hipLaunchKernelGGL((lin_dx_wide_kernel<float, float>), gridw, dim3(256), 0, st, dy, ldo, (const float*)w, (long long)ldw, (float*)dx,

@@ -422,8 +422,7 @@ static int wg_launch(WGArgs& a, hipStream_t st) {
   // that this traffic stays below ~1/4 of the MFMA time (estimated at 600 TFLOP/s), but keep >= 512 workgroups
   const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
   const long long cap = (long long)(flops * 5.4e-4 / (bco * bci * 4.0));
-  static const bool no_rowstep = getenv("DG_WG_GENERIC") != nullptr;
-  const bool rs = !no_rowstep && a.Wo % 32 == 0;
+  const bool rs = a.Wo % 32 == 0;
   // 64-pixel K-steps (half the barriers, half the resident workgroups) were measured equal to 32-pixel steps, and
   // 256x128 / 128x256 tiles (2 workgroups per CU, 25 % fewer staged bytes per flop) 8-20 % SLOWER than 128x128 with 3
   // workgroups per CU: neither is built.
@@ -1175,9 +1174,7 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
     return g->dtype == DG_F32 ? wg_launch_im2col<float>(a, st) : wg_launch_im2col<bf16_t>(a, st);
   // narrow row-of-taps kernel (wg3) against the per-tap kernel: +4-10 % with >= 2 input-channel tiles or multi-megapixel
   // batches, -20 % on the 128-channel 128^2 layers; the wide kernel (wg3w) takes every layer it is eligible for
-  static const bool no_rows = getenv("DG_WG_NOROWS") != nullptr;
-  static const bool no_wide = getenv("DG_WG_NOWIDE") != nullptr;
-  static const bool no_wide_s2 = no_wide || getenv("DG_WG_NOWIDES2") != nullptr;
+  constexpr bool no_rows = false, no_wide = false, no_wide_s2 = false;
   const bool wide = g->dtype == DG_BF16 && a.Cout >= 128 && a.Cin >= 128;
   // (the -20 % of the row-of-taps shape on 128-channel 128^2 layers was the narrow wg3 kernel with the old split rounding: the
   // wide kernel is +19-37 % there too)
@@ -1186,7 +1183,7 @@ extern "C" int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void
   const bool wide_s1 = rows && wide && !no_wide;
   // stride 2 on the wide kernel (x tile of 65 input pixels per 32 output pixels)
   const bool wide_s2 = !no_rows && !no_wide_s2 && wide && g->stride == 2 && a.Wo % 32 == 0 && !g->pixel_shuffle;
-  static const bool no_fused_db = getenv("DG_WG_NOFUSEDDB") != nullptr;
+  constexpr bool no_fused_db = false;
   const bool fused_db = db && (wide_s1 || wide_s2) && !g->pixel_shuffle && !no_fused_db;   // the wide kernel sums the adjoint itself
   if (db && !fused_db) {   // bias gradient as a separate column-sum pass over the adjoint
     if (g->pixel_shuffle) return DG_ERR_BAD_ARG;
