@@ -280,13 +280,18 @@ def summarise_kernels(prof, elapsed, steps, peak, args, per_layer, with_traffic=
                     "conv_only": {"tflops": round(ccf / ccs / 1e12, 2) if ccs > 0 else None,
                                   "mfma_frac": round(ccf / ccs / 1e12 / peak, 4) if ccs > 0 else None},
                     "alg_tflop_per_step": round(cf / steps / 1e12, 3)}
-    f8 = [t for t in agg if t.endswith(":k32")]
-    if f8:      # fp8 mode: the MXFP8 conv launches (quantisation of their operands included in the bracketed time)
-        ffl, fsec, fn = sum(agg[t][0] for t in f8), sum(agg[t][1] for t in f8), sum(agg[t][2] for t in f8)
-        roofline["fp8_kernel"] = {"kernel": "gg_halo4w_f8_kernel (MXFP8 conv forward / data gradient of the critic's wide layers, operand "
-                                            "quantisation included; with --dtype fp8 also the generator trunk's forward)", "bound": "mfma", "achieved": round(ffl / fsec / 1e12, 2),
-                                  "peak": MFMA_PEAK_TFLOPS["fp8"], "unit": "TFLOP/s", "frac": round(ffl / fsec / 1e12 / MFMA_PEAK_TFLOPS["fp8"], 4),
-                                  "launches": fn, "share_of_step": round(fsec / elapsed, 3)}
+    f8c = [t for t in agg if t.endswith(":k32")]
+    f8w = [t for t in agg if t.startswith("conv_wgrad_f8")]
+    if f8c:     # fp8 mode: the MXFP8 conv launches (quantisation of their operands included in the bracketed time) + the fp8 weight gradients
+        def rate(tags):
+            fl_, sec_, n_ = sum(agg[t][0] for t in tags), sum(agg[t][1] for t in tags), sum(agg[t][2] for t in tags)
+            return {"achieved": round(fl_ / sec_ / 1e12, 2) if sec_ > 0 else None, "frac": round(fl_ / sec_ / 1e12 / MFMA_PEAK_TFLOPS["fp8"], 4) if sec_ > 0 else None,
+                    "launches": n_, "share_of_step": round(sec_ / elapsed, 3)}
+        roofline["fp8_kernel"] = dict({"kernel": "every fp8 MFMA launch of the step: gg_halo4w_f8_kernel (MXFP8 conv forward / data gradient of the critic's wide "
+                                                 "layers, operand quantisation included; with --dtype fp8 also the generator trunk's forward) and wg3w_f8_kernel "
+                                                 "(uniform-scale E4M3 weight gradients of the critic's layers 1-7)", "bound": "mfma",
+                                       "peak": MFMA_PEAK_TFLOPS["fp8"], "unit": "TFLOP/s"}, **rate(f8c + f8w),
+                                      conv=rate(f8c), weight_gradient=rate(f8w) if f8w else None)
     return roofline, critic_stack, kernels
 
 

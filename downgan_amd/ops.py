@@ -420,9 +420,9 @@ class HipOps:
         assert xq.dtype == torch.uint8 and dyq.dtype == torch.uint8 and ex.dtype == torch.uint8 and ey.dtype == torch.uint8
         assert dw.dtype == torch.float32 and dw.numel() == cv.Cout * 9 * cv.Cin and ex.numel() == cv.Cin // 32 and ey.numel() == cv.Cout // 32
         g = self._geom(cv, pix_layout(xq)[0], pix_layout(dyq)[0])
-        check(self._timed("conv_wgrad", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad_f8(
+        check(self._timed("conv_wgrad_f8", self.conv_flops(cv), lambda: self.lib.dg_conv3x3_wgrad_f8(
             C.byref(g), _ptr(xq), _ptr(ex), _ptr(dyq), _ptr(ey), _ptr(dw), self._stream()),
-            float(xq.numel() + dyq.numel()), cv.net, self._geom_tag(cv) + ":f8"), "dg_conv3x3_wgrad_f8")
+            float(xq.numel() + dyq.numel()), cv.net, self._geom_tag(cv)), "dg_conv3x3_wgrad_f8")
 
     def conv_wgrad_dense(self, cvs, slab, us, dws, dbs):
         """Weight / bias gradients of all convs of a dense block: conv k (``cvs[k-1]``: k*F -> F channels) reads ``slab[..., :k*F]``,
