@@ -798,12 +798,18 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   }
   constexpr int XK = S2 ? 2 : 1;                                 // tile rows per output pixel
 
-  // bias gradient (column sums of the adjoint) on the side: the workgroups of the centre tap row and first input-channel
-  // tile already hold every adjoint fragment in registers; wave 0 adds them up (a lane's 8 values belong to one channel)
+  // bias gradient (column sums of the adjoint) on the side: every workgroup that stages this adjoint tile holds its fragments in
+  // registers.  The duty rotates over the K steps among the group of workgroups that share the tile and the pixel range (input
+  // tiles x 3 tap rows: step ks belongs to member ks mod group), and inside the workgroup wave w sums fragment w: left to wave 0
+  // of ONE workgroup per tile (round 2) those few workgroups ran 10-20 % longer than the rest of their round.  Deterministic mode keeps
+  // the single writer (one workgroup per split and tile adds into the split's copy: a fixed order).
   float* const db_out = a.tri ? (a.dbk[co_t] ? WG_DET_PTR(a, a.dbk[co_t], by) : nullptr)
                               : (a.db ? WG_DET_DB(a, by) + co0 : nullptr);         // bias gradient of this adjoint tile's rows
-  const bool do_db = db_out != nullptr && trow == 1 && ci_t == 0 && wave == 0;
-  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool has_db = db_out != nullptr;
+  const int db_group = a.det_ws ? 1 : 3 * (a.tri ? co_t + 1 : a.nci_t);
+  const bool db_member = a.det_ws ? (trow == 1 && ci_t == 0) : true;
+  int db_cnt = a.det_ws ? 0 : ci_t * 3 + trow;                  // steps until this workgroup's next turn
+  float dbacc = 0.f;
 
   issue(0, 0);
   if (nsteps > 1) issue(1, 1);
@@ -822,6 +828,8 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
     const bool ahead = ks + 2 < nsteps;
     int nb = cur + 2; if (nb >= 3) nb -= 3;
     if (ahead) issue(nb, ks + 2);            // buffer (ks + 2) % 3 was last read in step ks - 1, behind that step's barrier
+    const bool db_now = has_db && db_member && db_cnt == 0;
+    db_cnt = db_cnt == 0 ? db_group - 1 : db_cnt - 1;
     const unsigned char* sb = wgw_dsm + cur * BUFB;
     // input fragments are read one tap ahead of the MFMAs that use them (two fragment registers sets of 4): the LDS latency
     // of tap s+1 runs under the four MFMAs of tap s instead of in front of its own
@@ -844,12 +852,14 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
         const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         fa[f] = __builtin_bit_cast(bf16x8_t, v);
       }
-      if (do_db) {
+      if (db_now) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const u32x4w_t w4 = __builtin_bit_cast(u32x4w_t, fa[f]);
+          if (f == wave) {                           // (wave is uniform: a scalar branch; fa[] must be indexed at compile time)
+            const u32x4w_t w4 = __builtin_bit_cast(u32x4w_t, fa[f]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dbacc[f] += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);
+            for (int e = 0; e < 4; ++e) dbacc += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);
+          }
         }
       }
 #pragma unroll
@@ -870,11 +880,7 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
     if (++cur == 3) cur = 0;
   }
 
-  if (do_db) {
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-      if (co0 + 32 * f + r32 < a.Cout) atomicAdd(db_out + 32 * f + r32, dbacc[f]);
-  }
+  if (has_db && db_member && co0 + 32 * wave + r32 < a.Cout) atomicAdd(db_out + 32 * wave + r32, dbacc);
   // epilogue: one lane-constant 32-bit offset, everything else of an element's address is workgroup-uniform (scalar base)
   const int cin_w = a.tri ? (co_t + 1) * BCI : a.Cin;                  // input channels of the conv these rows belong to
   const int cow0 = a.tri ? 0 : co0;                                    // first gradient row of this tile inside that conv

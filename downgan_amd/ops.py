@@ -433,17 +433,17 @@ class HipOps:
         if not (self.dtype == "bf16" and F_ == 128 and cv0.W % 32 == 0 and all(c.Cin == (k + 1) * F_ and c.Cout == F_ and c.stride == 1 and not c.pixel_shuffle
                                                                               for k, c in enumerate(cvs))) or os.environ.get("DG_WG_NODENSE"):
             for k, c in enumerate(cvs):
-                self.conv_wgrad(c, slab[..., :(k + 1) * F_], us[..., k * F_:(k + 1) * F_], dws[k], db=dbs[k])
+                self.conv_wgrad(c, slab[..., :(k + 1) * F_], us[..., k * F_:(k + 1) * F_], dws[k], db=dbs[k] if dbs is not None else None)
             return
         self._act(slab); self._act(us)
         assert tuple(slab.shape) == (cv0.N, cv0.H, cv0.W, n * F_) and tuple(us.shape) == tuple(slab.shape)
         for k in range(n):
             assert dws[k].dtype == torch.float32 and dws[k].numel() == F_ * 9 * (k + 1) * F_ and dws[k].is_contiguous()
-            assert dbs[k].dtype == torch.float32 and dbs[k].numel() >= F_
+            assert dbs is None or (dbs[k].dtype == torch.float32 and dbs[k].numel() >= F_)
         cvv = Conv(cv0.N, cv0.H, cv0.W, n * F_, n * F_, net=cv0.net)
         g = self._geom(cvv, pix_layout(slab)[0], pix_layout(us)[0])
         pw = (C.c_void_p * n)(*[t.data_ptr() for t in dws])
-        pb = (C.c_void_p * n)(*[t.data_ptr() for t in dbs])
+        pb = (C.c_void_p * n)(*[t.data_ptr() for t in dbs]) if dbs is not None else None
         flops = sum(self.conv_flops(c) for c in cvs)
         nbytes = sum(self.conv_bytes(c) for c in cvs)
         check(self._timed("conv_wgrad", flops, lambda: self.lib.dg_conv3x3_wgrad_dense(
