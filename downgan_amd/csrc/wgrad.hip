@@ -30,7 +30,48 @@ struct WGArgs {
   // instead of the gradient itself: dw / dwk[] / dbk[] keep their offsets from det_base, db sits at det_db_off of the copy
   float* det_ws; const float* det_base; long long det_stride, det_db_off;
   const unsigned char* ex; const unsigned char* eu;   // fp8 kernel: E8M0 exponent byte per 32-channel block of x / of the adjoint
+  // wide kernels, > 72 tiles per pixel range: launch order in UNITS of `grp` tiles (a group of adjoint tiles x all input tiles x 3 tap
+  // rows of one pixel range) that stay on one XCD (wg_group_order)
+  int grp, ngrp, nunits, gtiles;
 };
+
+// > 72 tiles per pixel range (the 512 / 1024-channel layers): the plain XCD remap would put 96-192 workgroups that want the same
+// pixel range on 64 resident slots of one XCD (measured -5...-12 % in round 1); the launch order puts workgroup i on XCD i % 8, i.e.
+// tile index % 8 -- with the input tile as the fastest tile coordinate every XCD then owns 1 / 8 of the input tiles (or one of
+// 1 / 2 / 4) and reads ALL of the adjoint: fabric bytes ~ 8 dy + max(1, 8 / nci_t) x.  Alternative: units of <= 64 tiles -- cg
+// adjoint-channel tiles x all input tiles x 3 tap rows of one pixel range -- unit u on XCD u % 8, its tiles back to back: ~ dy +
+// ngrp x.  The cheaper estimate wins (rocprofv3 FETCH_SIZE, profiles/r04_wg_order_ab.log, batch 32: 512 -> 1024 at 128^2 11.0 -> 3.5 GB per
+// launch and +2.5 % (bf16) / +2 % (fp8) in time; 1024 -> 1024 stride 2 keeps the launch order: 3.9 GB against 10.3 grouped, -6 %).
+static void wg_group_order(WGArgs& a, int nco_t, int ntiles, int splits) {
+  a.grp = 0;
+  if (a.tri || ntiles <= 72) return;
+  const int per_co = 3 * a.nci_t;
+  int cg = 0;
+  for (int c = 1; c <= nco_t; ++c)
+    if (nco_t % c == 0 && c * per_co <= 64) cg = c;
+  if (!cg) return;
+  const double dy_b = (double)a.Mpix * a.Cout, x_b = (double)a.Mpix * a.stride * a.stride * a.Cin;
+  const double in_order = 8.0 * dy_b + x_b * (a.nci_t >= 8 ? 1.0 : 8.0 / a.nci_t), grouped = dy_b + x_b * (nco_t / cg);
+  if (grouped > 0.8 * in_order) return;
+  a.grp = cg * per_co; a.ngrp = nco_t / cg; a.nunits = splits * a.ngrp; a.gtiles = ntiles;
+}
+// number of workgroups of a grouped launch: every XCD gets the same number of unit slots
+static unsigned wg_group_blocks(const WGArgs& a) { return 8u * (unsigned)((a.nunits + 7) / 8) * (unsigned)a.grp; }
+
+// decode of a workgroup's (tile, pixel split); false = a padding workgroup of a grouped launch
+__device__ __forceinline__ bool wg_decode(const WGArgs& a, int& bx, int& by) {
+  const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+  if (a.grp) {
+    const unsigned xcd = lin0 & 7u, slot = lin0 >> 3;
+    const unsigned unit = (slot / (unsigned)a.grp) * 8u + xcd, within = slot % (unsigned)a.grp;
+    if (unit >= (unsigned)a.nunits) return false;
+    by = (int)(unit / (unsigned)a.ngrp); bx = (int)((unit % (unsigned)a.ngrp) * (unsigned)a.grp + within);
+    return true;
+  }
+  const unsigned lin = gridDim.x <= 72 ? xcd_remap(lin0, gridDim.x * gridDim.y) : lin0;
+  bx = (int)(lin % gridDim.x); by = (int)(lin / gridDim.x);
+  return true;
+}
 #define WG_DET_PTR(a, p, by) ((a).det_ws ? (a).det_ws + (long long)(by) * (a).det_stride + ((p) - (a).det_base) : (p))
 #define WG_DET_DB(a, by) ((a).det_ws ? (a).det_ws + (long long)(by) * (a).det_stride + (a).det_db_off : (a).db)
 
@@ -693,9 +734,8 @@ __global__ __launch_bounds__(256, 2) void wg3w_kernel(const WGArgs a) {
   constexpr int ROWB = 256, SU_B = KP * ROWB, SX_B = XALLOC * ROWB, BUFB = SU_B + SX_B;
   extern __shared__ __attribute__((aligned(16))) unsigned char wgw_dsm[];            // 3 * BUFB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
-  const unsigned lin = gridDim.x <= 72 ? xcd_remap(lin0, gridDim.x * gridDim.y) : lin0;
-  const int bx = (int)(lin % gridDim.x), by = (int)(lin / gridDim.x);
+  int bx, by;
+  if (!wg_decode(a, bx, by)) return;
   int ci_t = bx % a.nci_t;
   int trow = (bx / a.nci_t) % 3;
   int co_t = bx / (a.nci_t * 3);
@@ -919,7 +959,8 @@ static int wg3w_launch(WGArgs& a, hipStream_t st) {
   if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb);
   constexpr int lds = 3 * (32 * 256 + (S2 ? 68 : 36) * 256);
   if (lds > 65536) DG_SET_MAX_LDS_ONCE((&wg3w_kernel<S2>), lds);
-  hipLaunchKernelGGL((wg3w_kernel<S2>), dim3(ntiles, splits), dim3(256), lds, st, a);
+  wg_group_order(a, nco_t, ntiles, splits);
+  hipLaunchKernelGGL((wg3w_kernel<S2>), a.grp ? dim3(wg_group_blocks(a)) : dim3(ntiles, splits), dim3(256), lds, st, a);
   if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
   return wg_det_end(a, plan, lo, span, st);
 }
@@ -955,9 +996,8 @@ __global__ __launch_bounds__(256, 2) void wg3w_f8_kernel(const WGArgs a) {
   constexpr int SU_B = KP * ROWB, SX_B = XPIECES * XPITCH, BUFB = SU_B + SX_B;
   extern __shared__ __attribute__((aligned(16))) unsigned char wg8_dsm[];          // 3 * BUFB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned lin0 = blockIdx.y * gridDim.x + blockIdx.x;
-  const unsigned lin = gridDim.x <= 72 ? xcd_remap(lin0, gridDim.x * gridDim.y) : lin0;
-  const int bx = (int)(lin % gridDim.x), by = (int)(lin / gridDim.x);
+  int bx, by;
+  if (!wg_decode(a, bx, by)) return;
   const int ci_t = bx % a.nci_t, trow = (bx / a.nci_t) % 3, co_t = bx / (a.nci_t * 3);
   const int co0 = co_t * BCO, ci0 = ci_t * BCI;
   const int dr = trow - 1;
@@ -1137,13 +1177,15 @@ extern "C" int dg_conv3x3_wgrad_f8(const dg_conv_geom* g, const void* xq, const 
   const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
   if (granted < 0) return DG_ERR_LAUNCH;
   if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb);
+  wg_group_order(a, nco_t, ntiles, splits);
+  const dim3 grid = a.grp ? dim3(wg_group_blocks(a)) : dim3(ntiles, splits);
   if (g->stride == 2) {
     constexpr int lds2 = 3 * (64 * 128 + 17 * 1152);
     DG_SET_MAX_LDS_ONCE((&wg3w_f8_kernel<true>), lds2);
-    hipLaunchKernelGGL(wg3w_f8_kernel<true>, dim3(ntiles, splits), dim3(256), lds2, st, a);
+    hipLaunchKernelGGL(wg3w_f8_kernel<true>, grid, dim3(256), lds2, st, a);
   } else {
     constexpr int lds = 3 * (64 * 128 + 9 * 1024);
-    hipLaunchKernelGGL(wg3w_f8_kernel<false>, dim3(ntiles, splits), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(wg3w_f8_kernel<false>, grid, dim3(256), lds, st, a);
   }
   if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
   return wg_det_end(a, plan, lo, span, st);
