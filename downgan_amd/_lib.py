@@ -84,11 +84,13 @@ _PROTOS = {
     "dg_conv3x3_wgrad": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp],
     "dg_conv3x3_wgrad_dense": [_vp, _i, _vp, _vp, _vp, _vp, _vp],
     "dg_conv3x3_wgrad_f8": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp, _vp],
+    "dg_conv3x3_wgrad_dense_f8": [C.POINTER(ConvGeom), _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "dg_gather_gemm": [C.POINTER(GGDesc), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_plan": [C.POINTER(ConvGeom), _i, C.POINTER(GGDesc)],
     "dg_last_conv_kernels": [],
     "dg_conv3x3_dgrad_launches": [C.POINTER(ConvGeom)],
     "dg_colsum": [_i, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp],
+    "dg_colsum_multi": [_i, _vp, _i64, _i64, _i, _i, _vp, _vp],
     "dg_repack_conv_weights": [_i, _i, _vp, _vp, _i, _i, _vp],
     "dg_repack_dense_dgrad": [_i, _vp, _i, _i, _vp, _vp],
     "dg_wgrad_unswap": [_vp, _vp, _i, _i, _vp],

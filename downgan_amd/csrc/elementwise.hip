@@ -332,9 +332,10 @@ extern "C" int dg_sqdiff(int dtype, const void* a, int64_t lda, const void* b, i
 }
 
 // ------------------------------------------------------------------ column sum (bias gradients)
+struct ColsumDst { float* p[8]; int seg; };     // column c accumulates into p[c / seg][c % seg] (one destination: seg = C)
 template <typename T, int UNR>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* dy, long long ld_outer, int rows_inner, long long ld, int rows,
-                                                      int cchunks, int rows_per_block, float* db, float* det_ws, long long det_stride) {
+                                                      int cchunks, int rows_per_block, const ColsumDst dst, float* det_ws, long long det_stride) {
   // HBM-bound pass: every thread keeps UNR independent 16-byte loads in flight (a one-load-per-iteration loop with a
   // 64-bit division in it ran at 0.6 TB/s)
   constexpr int EPC = DT<T>::EPC;
@@ -373,8 +374,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* dy, long long ld_o
 #pragma unroll
       for (int e = 0; e < EPC; ++e) s[e] += red[(t * cchunks + tx) * EPC + e];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) atomicAdd((det_ws ? det_ws + blockIdx.x * det_stride : db) + tx * EPC + e, s[e]);
+    for (int e = 0; e < EPC; ++e) {
+      const int c = tx * EPC + e;
+      atomicAdd(det_ws ? det_ws + blockIdx.x * det_stride + c : dst.p[c / dst.seg] + c % dst.seg, s[e]);
+    }
   }
+}
+static int colsum_launch(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, int64_t rows_inner, int64_t ld, int C,
+                         const ColsumDst& dst, long long max_blocks, hipStream_t st) {
+  const long long rows = (long long)rows_outer * rows_inner;
+  long long nb = rows / 256;
+  if (nb < 1) nb = 1;
+  if (nb > max_blocks) nb = max_blocks;
+  DetPlan plan;
+  if (dg_det_begin(C, (int)nb, st, &plan) != DG_OK) return DG_ERR_LAUNCH;
+  nb = plan.copies;
+  const long long rpb = (rows + nb - 1) / nb;
+  nb = (rows + rpb - 1) / rpb;
+  if (dtype == DG_F32) hipLaunchKernelGGL((colsum_kernel<float, 8>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)dy, ld_outer, (int)rows_inner, ld, (int)rows, C / 4, (int)rpb, dst, plan.ws, plan.stride);
+  else hipLaunchKernelGGL((colsum_kernel<bf16_t, 8>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy, ld_outer, (int)rows_inner, ld, (int)rows, C / 8, (int)rpb, dst, plan.ws, plan.stride);
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  for (int k = 0; k * dst.seg < C; ++k) {
+    const int rc = dg_det_reduce(plan, (long long)k * dst.seg, dst.p[k], dst.seg, st);
+    if (rc != DG_OK) return rc;
+  }
+  return DG_OK;
 }
 extern "C" int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, int64_t rows_inner, int64_t ld,
                          int C, float* db, void* stream) {
@@ -382,22 +406,25 @@ extern "C" int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t 
   const long long rows = (long long)rows_outer * rows_inner;
   const int epc = dtype == DG_F32 ? 4 : 8;
   if (C / epc > 256 || rows >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype != DG_F32 && dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
   // few, long workgroups: the pass is bound by the final same-address atomics, not by HBM (134 MB bf16, measured:
   // 4096 blocks 404 us, 1024 214 us (old kernel), 512 116 us, 256 72 us, 128 62 us)
-  long long nb = rows / 256;
-  if (nb < 1) nb = 1;
-  if (nb > 128) nb = 128;
+  ColsumDst dst{};
+  dst.p[0] = db; dst.seg = C;
+  return colsum_launch(dtype, dy, rows_outer, ld_outer, rows_inner, ld, C, dst, 128, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Column sums of ONE pass over a wide tensor into nseg destinations: db[k][c] += sum over rows of dy[row, k * (C / nseg) + c] -- the five
+// bias gradients of a dense block from its adjoint slab [N*H*W, 5 * 128] (generator.py:24-41), rows of `ld` elements.
+extern "C" int dg_colsum_multi(int dtype, const void* dy, int64_t rows, int64_t ld, int C, int nseg, float* const* db, void* stream) {
+  if (!dy || !db || rows <= 0 || C <= 0 || nseg < 1 || nseg > 8 || C % nseg || (C / nseg) % 8 || ld % 8 || rows >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
   if (dtype != DG_F32 && dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
-  DetPlan plan;
-  if (dg_det_begin(C, (int)nb, st, &plan) != DG_OK) return DG_ERR_LAUNCH;
-  nb = plan.copies;
-  const long long rpb = (rows + nb - 1) / nb;
-  nb = (rows + rpb - 1) / rpb;
-  if (dtype == DG_F32) hipLaunchKernelGGL((colsum_kernel<float, 8>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)dy, ld_outer, (int)rows_inner, ld, (int)rows, C / 4, (int)rpb, db, plan.ws, plan.stride);
-  else hipLaunchKernelGGL((colsum_kernel<bf16_t, 8>), dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)dy, ld_outer, (int)rows_inner, ld, (int)rows, C / 8, (int)rpb, db, plan.ws, plan.stride);
-  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
-  return dg_det_reduce(plan, 0, db, C, st);
+  if (C / (dtype == DG_F32 ? 4 : 8) > 256) return DG_ERR_BAD_SHAPE;
+  ColsumDst dst{};
+  for (int k = 0; k < nseg; ++k) { if (!db[k]) return DG_ERR_BAD_ARG; dst.p[k] = db[k]; }
+  dst.seg = C / nseg;
+  // the atomics spread over nseg times the addresses of a 128-column pass: as many more workgroups
+  return colsum_launch(dtype, dy, rows, ld, 1, ld, C, dst, 128ll * nseg, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------ small head helpers

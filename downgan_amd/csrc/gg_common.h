@@ -555,6 +555,11 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       case 257: run(std::integral_constant<int, 257>{}, htag); break;  // fp8 mode: bias + LeakyReLU + MXFP8 copy (generator dense-block convs)
       case 264: run(std::integral_constant<int, 264>{}, htag); break;  // fp8 mode: residual + MXFP8 copy (dense-block output)
       case 280: run(std::integral_constant<int, 280>{}, htag); break;  // fp8 mode: two residuals + MXFP8 copy (RRDB output)
+      case 288: run(std::integral_constant<int, 288>{}, htag); break;  // fp8 mode: activation mask + MXFP8 copy (generator dense-block data gradients)
+      case 2305: run(std::integral_constant<int, 2305>{}, htag); break; // 257 / 264 / 280 / 288 + the uniform-scale copy (+ 2048) for the dense blocks' fp8 weight gradient
+      case 2312: run(std::integral_constant<int, 2312>{}, htag); break;
+      case 2328: run(std::integral_constant<int, 2328>{}, htag); break;
+      case 2336: run(std::integral_constant<int, 2336>{}, htag); break;
       case 258: run(std::integral_constant<int, 258>{}, htag); break;  // fp8 mode: 1-bit mask + MXFP8 copy (critic data gradients, tangent forward)
       case 261: run(std::integral_constant<int, 261>{}, htag); break;  // fp8 mode: LeakyReLU + out_bits + MXFP8 copy (critic forward)
       case 2306: run(std::integral_constant<int, 2306>{}, htag); break; // ... + the uniform-scale copy for the fp8 weight gradient (258 + 2048)

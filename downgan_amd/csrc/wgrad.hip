@@ -998,7 +998,14 @@ __global__ __launch_bounds__(256, 2) void wg3w_f8_kernel(const WGArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, by;
   if (!wg_decode(a, bx, by)) return;
-  const int ci_t = bx % a.nci_t, trow = (bx / a.nci_t) % 3, co_t = bx / (a.nci_t * 3);
+  int ci_t = bx % a.nci_t, trow = (bx / a.nci_t) % 3, co_t = bx / (a.nci_t * 3);
+  if (a.tri) {                                  // dense-block mode as in wg3w_kernel: bx = 3 * pair + tap row, input tile <= adjoint tile
+    trow = bx % 3;
+    const int p = bx / 3;
+    co_t = 0;
+    while ((co_t + 1) * (co_t + 2) / 2 <= p) ++co_t;
+    ci_t = p - co_t * (co_t + 1) / 2;
+  }
   const int co0 = co_t * BCO, ci0 = ci_t * BCI;
   const int dr = trow - 1;
   const int pbeg = by * a.ppb;
@@ -1129,10 +1136,12 @@ __global__ __launch_bounds__(256, 2) void wg3w_f8_kernel(const WGArgs a) {
   }
 
   // epilogue (wg3w_kernel's): one lane-constant 32-bit offset, the rest of an element's address is workgroup-uniform
-  float* const dw_out = WG_DET_PTR(a, a.dw, by);
-  const long long ldw = 9ll * a.Cin;
+  const int cin_w = a.tri ? (co_t + 1) * BCI : a.Cin;                  // input channels of the conv these rows belong to
+  const int cow0 = a.tri ? 0 : co0;                                    // first gradient row of this tile inside that conv
+  float* const dw_out = WG_DET_PTR(a, a.tri ? a.dwk[co_t] : a.dw, by);
+  const long long ldw = 9ll * cin_w;
   const int ci = ci0 + wave * 32 + r32;
-  const unsigned lane_off = (unsigned)((((long long)co0 + 4 * h) * ldw + ci) * 4);
+  const unsigned lane_off = (unsigned)((((long long)cow0 + 4 * h) * ldw + ci) * 4);
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     const int tap = trow * 3 + s;
@@ -1141,10 +1150,38 @@ __global__ __launch_bounds__(256, 2) void wg3w_f8_kernel(const WGArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int cor = 32 * f + (reg & 3) + 8 * (reg >> 2);             // + co0 + 4h
-        char* const base = reinterpret_cast<char*>(dw_out) + ((long long)cor * ldw + (long long)tap * a.Cin) * 4;
+        char* const base = reinterpret_cast<char*>(dw_out) + ((long long)cor * ldw + (long long)tap * cin_w) * 4;
         atomicAdd(reinterpret_cast<float*>(base + lane_off), acc[s][f][reg]);
       }
   }
+}
+
+// launch of the fp8 kernel for a prepared WGArgs (x / u / ex / eu / geometry / Mpix set; tri + dwk[] in dense-block mode)
+static int wg3w_f8_launch(WGArgs& a, hipStream_t st) {
+  constexpr int BCO = 128, BCI = 128;
+  const int nco_t = a.Cout / BCO;
+  a.nci_t = a.Cin / BCI;
+  const int npairs = a.tri ? nco_t * (nco_t + 1) / 2 : nco_t * a.nci_t;
+  const int ntiles = 3 * npairs;
+  const double flops = 2.0 * 9 * BCO * (double)BCI * npairs * a.Mpix;
+  const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // the atomics-traffic budget of the bf16 launchers
+  int splits = wg_pick_splits(ntiles, 1536, cap, a.Mpix, &a.ppb);                   // 3 rounds of 512 slots (2 per CU)
+  DetPlan plan; float* lo = nullptr; long long span = 0;
+  const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
+  if (granted < 0) return DG_ERR_LAUNCH;
+  if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb);
+  wg_group_order(a, nco_t, ntiles, splits);
+  const dim3 grid = a.grp ? dim3(wg_group_blocks(a)) : dim3(ntiles, splits);
+  if (a.stride == 2) {
+    constexpr int lds2 = 3 * (64 * 128 + 17 * 1152);
+    DG_SET_MAX_LDS_ONCE((&wg3w_f8_kernel<true>), lds2);
+    hipLaunchKernelGGL(wg3w_f8_kernel<true>, grid, dim3(256), lds2, st, a);
+  } else {
+    constexpr int lds = 3 * (64 * 128 + 9 * 1024);
+    hipLaunchKernelGGL(wg3w_f8_kernel<false>, grid, dim3(256), lds, st, a);
+  }
+  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
+  return wg_det_end(a, plan, lo, span, st);
 }
 
 // dw[co][tap][ci] (fp32, accumulated into) += sum_p dy[p, co] * x[src(p, tap), ci] for E4M3 operands with per-32-channel-block
@@ -1165,30 +1202,31 @@ extern "C" int dg_conv3x3_wgrad_f8(const dg_conv_geom* g, const void* xq, const 
   const long long mp = (long long)g->N * a.Ho * a.Wo;
   if (mp >= (1ll << 31) || (long long)(a.W + 8) * a.ldx >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
   a.Mpix = (int)mp;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  constexpr int BCO = 128, BCI = 128;
-  const int nco_t = a.Cout / BCO;
-  a.nci_t = a.Cin / BCI;
-  const int ntiles = 3 * nco_t * a.nci_t;
-  const double flops = 2.0 * 9 * a.Cin * (double)a.Cout * a.Mpix;
-  const long long cap = (long long)(flops * 5.4e-4 / (3.0 * BCO * BCI * 4.0));     // the atomics-traffic budget of the bf16 launchers
-  int splits = wg_pick_splits(ntiles, 1536, cap, a.Mpix, &a.ppb);                   // 3 rounds of 512 slots (2 per CU)
-  DetPlan plan; float* lo = nullptr; long long span = 0;
-  const int granted = wg_det_begin(a, splits, st, &plan, &lo, &span);
-  if (granted < 0) return DG_ERR_LAUNCH;
-  if (granted != splits) splits = wg_pick_splits(ntiles, (long long)ntiles * granted, 1ll << 40, a.Mpix, &a.ppb);
-  wg_group_order(a, nco_t, ntiles, splits);
-  const dim3 grid = a.grp ? dim3(wg_group_blocks(a)) : dim3(ntiles, splits);
-  if (g->stride == 2) {
-    constexpr int lds2 = 3 * (64 * 128 + 17 * 1152);
-    DG_SET_MAX_LDS_ONCE((&wg3w_f8_kernel<true>), lds2);
-    hipLaunchKernelGGL(wg3w_f8_kernel<true>, grid, dim3(256), lds2, st, a);
-  } else {
-    constexpr int lds = 3 * (64 * 128 + 9 * 1024);
-    hipLaunchKernelGGL(wg3w_f8_kernel<false>, grid, dim3(256), lds, st, a);
-  }
-  if (dg_check_launch() != DG_OK) return DG_ERR_LAUNCH;
-  return wg_det_end(a, plan, lo, span, st);
+  return wg3w_f8_launch(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The dense-block launch (dg_conv3x3_wgrad_dense) on the fp8 kernel: xq / dyq = uniform-scale E4M3 copies of the activation and
+// adjoint slabs [N, H, W, nconv * 128] (pixel strides g->ldx / g->ldy in bytes), ex / ey = their nconv * 4 block exponents; weight
+// gradients only (the bias gradients are column sums of the adjoint: dg_colsum).  W % 64 == 0.
+extern "C" int dg_conv3x3_wgrad_dense_f8(const dg_conv_geom* g, int nconv, const void* xq, const void* ex, const void* dyq, const void* ey,
+                                         float* const* dw, void* stream) {
+  if (!g || !xq || !ex || !dyq || !ey || !dw) return DG_ERR_BAD_ARG;
+  if (g->dtype != DG_BF16) return DG_ERR_BAD_DTYPE;
+  if (nconv < 1 || nconv > 8 || g->N <= 0 || g->H <= 0 || g->W <= 0 || g->stride != 1 || g->pixel_shuffle || g->W % 64) return DG_ERR_BAD_SHAPE;
+  if (g->Cin != nconv * 128 || g->Cout != nconv * 128 || g->ldx % 16 || g->ldy % 16 || g->ldx < g->Cin || g->ldy < g->Cout) return DG_ERR_BAD_SHAPE;
+  for (int k = 0; k < nconv; ++k)
+    if (!dw[k]) return DG_ERR_BAD_ARG;
+  WGArgs a{};
+  a.x = xq; a.u = dyq; a.dw = dw[0]; a.ldx = g->ldx; a.ldu = g->ldy;
+  a.ex = (const unsigned char*)ex; a.eu = (const unsigned char*)ey;
+  a.H = g->H; a.W = g->W; a.stride = 1; a.Ho = g->H; a.Wo = g->W;
+  a.Cin = g->Cin; a.Cout = g->Cout; a.u_ps = 0; a.cps_chunks = 1;
+  const long long mp = (long long)g->N * a.Ho * a.Wo;
+  if (mp >= (1ll << 31) || (long long)(a.W + 8) * a.ldx >= (1ll << 31)) return DG_ERR_BAD_SHAPE;
+  a.Mpix = (int)mp;
+  a.tri = 1;
+  for (int k = 0; k < nconv; ++k) { a.dwk[k] = dw[k]; a.dbk[k] = nullptr; }
+  return wg3w_f8_launch(a, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, int64_t rows_inner, int64_t ld, int C,

@@ -686,6 +686,17 @@ class NativeGenerator:
         self.cv_v = [Conv(B, S, S, F_, (5 - j) * F_, net="G") for j in range(5)]
         self._vsize = [(5 - j) * F_ * 9 * F_ for j in range(5)]
         self._vpack = [o.zeros(sum(self._vsize)) for _ in range(self.ndrb)]
+        # fp8 mode: the dense blocks' DATA GRADIENTS on the MXFP8 kernel too (their reduction runs over the stacked adjoint channels:
+        # the adjoint slab gets an MXFP8 form written by the producing epilogues, the virtual packs are quantised after every step)
+        self.f8_bwd = self.f8 and bool(getattr(o, "f8_gbwd", False)) and all(o.f8_eligible(cv, "dgrad") for cv in self.cv_v)
+        # ... and their WEIGHT GRADIENTS on the fp8 kernel (dg_conv3x3_wgrad_dense_f8; critic: NativeCritic.wg8): uniform-scale E4M3 copies
+        # of every saved activation slab and of the two rotating adjoint slabs, written by the producing epilogues (out_u) with the
+        # block exponents the PREVIOUS generator iteration's tensors reached (delayed scaling: `_ex` / `_eu` [block][5F / 32], refreshed
+        # at the end of backward from the `_new` sets collected during the pass); until a first iteration has produced exponents the
+        # bf16 kernel runs.  Bias gradients: column sums of the bf16 adjoint slices.
+        self.f8_wg = (self.f8_bwd and bool(getattr(o, "f8_wgrad", False)) and bool(getattr(o, "f8_gwgrad", False)) and F_ == 128 and S % 64 == 0)
+        self._slab_u = self._us_u = self._ex = self._eu = self._ex_new = self._eu_new = None
+        self._u_ok = self._u_live = False
         P.after_refresh.append(self._rebuild_vpacks)
         if self.f8:
             P.after_refresh.append(self._requantise_weights)
@@ -750,6 +761,16 @@ class NativeGenerator:
         for d in range(self.ndrb):
             pre = f"res_blocks.{d // 3}.dense_blocks.{d % 3}.b"
             o.repack_dense([P.view(P.p, f"{pre}{k}.0.weight").reshape(-1) for k in range(1, 6)], self._vpack[d], self.F)
+        if self.f8_bwd:          # MXFP8 forms of the virtual data-gradient packs [F * 9][(5 - j) F] (reduction = the stacked adjoint channels)
+            F_ = self.F
+            if self._vq is None:
+                self._vq = [[(o.zeros(F_ * 9, (5 - j) * F_, dtype=torch.uint8), o.zeros(F_ * 9, (5 - j) * F_ // 32, dtype=torch.uint8)) for j in range(5)]
+                            for _ in range(self.ndrb)]
+            for d in range(self.ndrb):
+                for j in range(5):
+                    o.quant_mxfp8(self.vpack(d, j).view(F_ * 9, (5 - j) * F_), *self._vq[d][j])
+
+    _vq = None
 
     # ---- forward -----------------------------------------------------------------------------------
     def _slab(self, d, save):
@@ -778,6 +799,22 @@ class NativeGenerator:
             return self._qring[d % 4][0][..., c0:c1], self._qring[d % 4][1][..., c0 // 32:c1 // 32]
         if f8:
             o.quant_mxfp8(self._slab(0, save)[..., :F_], *qs(0, 0, F_))
+        # fp8 weight gradients: this (saved) pass writes the uniform-scale copies of its slabs when exponents exist, and collects the
+        # exponents for the next generator iteration either way
+        wg8 = self.f8_wg and save
+        if wg8 and self._slab_u is None:
+            nb = 5 * F_ // 32
+            self._slab_u = [o.zeros(self.B, self.S, self.S, 5 * F_, dtype=torch.uint8) for _ in range(self.ndrb)]
+            self._us_u = [o.zeros(self.B, self.S, self.S, 5 * F_, dtype=torch.uint8) for _ in range(2)]
+            self._ex, self._eu, self._ex_new, self._eu_new = (o.zeros(self.ndrb, nb, dtype=torch.uint8) for _ in range(4))
+        u_live = wg8 and self._u_ok
+        if save:
+            self._u_live = u_live
+        def su(d, c0, c1):
+            """out_u operand for channels [c0, c1) of saved slab d: (bytes, this pass's exponents of those blocks)"""
+            return self._slab_u[d][..., c0:c1], self._ex[d][c0 // 32:c1 // 32]
+        if u_live:
+            o.quant_uniform(self._slab(0, save)[..., :F_], *su(0, 0, F_))
         for i in range(self.nrb):
             rrdb_in = self._slab(3 * i, save)[..., :F_]
             for j in range(3):
@@ -786,6 +823,8 @@ class NativeGenerator:
                 pre = f"res_blocks.{i}.dense_blocks.{j}.b"
                 for k in range(1, 5):
                     kw = dict(xq=qs(d, 0, k * F_), wq=self._wq[f"{pre}{k}.0"], out_q=qs(d, k * F_, (k + 1) * F_)) if f8 else {}
+                    if u_live:
+                        kw["out_u"] = su(d, k * F_, (k + 1) * F_)
                     o.conv_fwd(self.cv_b[k - 1], slab[..., :k * F_], W(f"{pre}{k}.0"), slab[..., k * F_:(k + 1) * F_],
                                bias=Bz(f"{pre}{k}.0"), act=G_SLOPE, **kw)
                 ep = dict(bias=Bz(f"{pre}5.0"), r1=slab[..., :F_], s1=RES_SCALE)          # generator.py:41
@@ -793,7 +832,11 @@ class NativeGenerator:
                     ep.update(r2=rrdb_in, s2=RES_SCALE)                                  # generator.py:53
                 if f8:
                     ep.update(xq=qs(d, 0, 5 * F_), wq=self._wq[f"{pre}5.0"], out_q=qs(d + 1, 0, F_))
+                    if u_live and d + 1 < self.ndrb:
+                        ep["out_u"] = su(d + 1, 0, F_)
                 o.conv_fwd(self.cv_b[4], slab, W(f"{pre}5.0"), nxt[..., :F_], **ep)
+            if wg8:      # the RRDB's three slabs are complete in the fp8 ring (four entries: the conv above wrote slice 0 of a fourth)
+                o.block_exp_max_batch([(self._qring[d % 4][1], self._ex_new[d]) for d in range(3 * i, 3 * i + 3)])
         kw = dict(xq=qs(self.ndrb, 0, F_), wq=self._wq["conv2"]) if f8 else {}
         o.conv_fwd(self.cv_conv2, self._slab(self.ndrb, save)[..., :F_], W("conv2"), self.trunk, bias=Bz("conv2"),
                    r1=self.out1, s1=1.0, **kw)                                           # generator.py:86-87
@@ -817,6 +860,14 @@ class NativeGenerator:
                 d_trunk=o.zeros(B, S, S, F_), gy=[o.zeros(B, S, S, F_), o.zeros(B, S, S, F_)],
                 gx=o.zeros(B, S, S, F_), us=[o.zeros(B, S, S, 5 * F_), o.zeros(B, S, S, 5 * F_)])
         bw = self._bwd
+        f8b = self.f8_bwd
+        if f8b and "usq" not in bw:
+            bw["usq"] = [(o.zeros(B, S, S, 5 * F_, dtype=torch.uint8), o.zeros(B, S, S, 5 * F_ // 32, dtype=torch.uint8)) for _ in range(2)]
+        usq = lambda di, c0, c1: (bw["usq"][di][0][..., c0:c1], bw["usq"][di][1][..., c0 // 32:c1 // 32])
+        # fp8 weight gradients: the forward wrote valid uniform-scale slab copies -> this pass writes the adjoint slabs' (block d's with
+        # block d's exponents: the two byte buffers rotate, the exponent sets do not) and runs the fp8 kernel
+        u_live = self.f8_wg and self._u_live
+        uu = lambda d, c0, c1: (self._us_u[d & 1][..., c0:c1], self._eu[d][c0 // 32:c1 // 32])
         W = lambda n: P.w(n + ".weight")
         WD = lambda n: P.wd(n + ".weight")
         GW = lambda n: P.grad(n + ".weight").reshape(-1)
@@ -862,6 +913,10 @@ class NativeGenerator:
             # adjoint of conv 5's output, o = 0.2*b5 + x), written by the PREVIOUS block's last data gradient straight into this
             # block's adjoint slab: no separate scaling pass per block.
             o.axpby(bw["us"][(3 * i + 2) & 1][..., 4 * F_:], gy, RES_SCALE * RES_SCALE)
+            if f8b:        # (the one adjoint slice of an RRDB that does not come out of a conv epilogue)
+                o.quant_mxfp8(bw["us"][(3 * i + 2) & 1][..., 4 * F_:], *usq((3 * i + 2) & 1, 4 * F_, 5 * F_))
+                if u_live:
+                    o.quant_uniform(bw["us"][(3 * i + 2) & 1][..., 4 * F_:], *uu(3 * i + 2, 4 * F_, 5 * F_))
             for j in (2, 1, 0):
                 d = 3 * i + j
                 # adjoint slab: channels [(k-1)F, kF) = u_k, the adjoint of conv k's output (k = 1..5)
@@ -870,16 +925,36 @@ class NativeGenerator:
                 for k in range(4, 0, -1):
                     # u_k = LeakyReLU'(b_k) * sum_{m > k} W_m[:, slice k]^T (*) u_m: one data gradient over u_{k+1..5}
                     uk = us[..., (k - 1) * F_:k * F_]
-                    o.conv_dgrad(self.cv_v[k], us[..., k * F_:], self.vpack(d, k), uk, mask=slab[..., k * F_:(k + 1) * F_], mask_slope=G_SLOPE)
+                    kw = dict(xq=usq(d & 1, k * F_, 5 * F_), wq=self._vq[d][k], out_q=usq(d & 1, (k - 1) * F_, k * F_)) if f8b else {}
+                    if u_live:
+                        kw["out_u"] = uu(d, (k - 1) * F_, k * F_)
+                    o.conv_dgrad(self.cv_v[k], us[..., k * F_:], self.vpack(d, k), uk, mask=slab[..., k * F_:(k + 1) * F_], mask_slope=G_SLOPE, **kw)
                 # the block's five weight / bias gradients, wgrad(slab[:kF], u_k): one launch over the 15 (u tile, slab tile) pairs
-                o.conv_wgrad_dense(self.cv_b, slab, us, [GW(f"{pre}{k}.0") for k in range(1, 6)], [GB(f"{pre}{k}.0") for k in range(1, 6)])
+                if u_live:
+                    o.conv_wgrad_dense_f8(self.cv_b, self._slab_u[d], self._ex[d], self._us_u[d & 1], self._eu[d], [GW(f"{pre}{k}.0") for k in range(1, 6)])
+                    o.colsum_multi(us, [GB(f"{pre}{k}.0") for k in range(1, 6)])
+                else:
+                    o.conv_wgrad_dense(self.cv_b, slab, us, [GW(f"{pre}{k}.0") for k in range(1, 6)], [GB(f"{pre}{k}.0") for k in range(1, 6)])
+                if self.f8_wg:     # the adjoint slab is complete: exponents for the next generator iteration's copies of it
+                    o.block_exp_max(bw["usq"][d & 1][1], self._eu_new[d])
                 # d x_drb = sum_m W_m[:, slice 0]^T (*) u_m + d o (identity path) = d o of the previous dense block; stored as that
                 # block's u5 = 0.2 * (sum + d o) = 0.2 * sum + this block's u5
                 nxt = bw["us"][(d - 1) & 1][..., 4 * F_:] if j > 0 else bw["gx"]
-                o.conv_dgrad(self.cv_v[0], us, self.vpack(d, 0), nxt, r1=us[..., 4 * F_:], s1=RES_SCALE)
+                kw = {}
+                if f8b:
+                    kw = dict(xq=usq(d & 1, 0, 5 * F_), wq=self._vq[d][0])
+                    if j > 0:
+                        kw["out_q"] = usq((d - 1) & 1, 4 * F_, 5 * F_)
+                        if u_live:
+                            kw["out_u"] = uu(d - 1, 4 * F_, 5 * F_)
+                o.conv_dgrad(self.cv_v[0], us, self.vpack(d, 0), nxt, r1=us[..., 4 * F_:], s1=RES_SCALE, **kw)
             gyn = bw["gy"][gyi ^ 1]
             o.axpby(gyn, bw["gx"], 1.0 / RES_SCALE, gy, 1.0)   # d x_rrdb = d x_drb(3i) + d y (identity path); gx holds 0.2 * d x_drb
             gy, gyi = gyn, gyi ^ 1
+        if self.f8_wg and self._ex_new is not None:      # every copy written with the old exponents has been consumed
+            self._ex.copy_(self._ex_new); self._eu.copy_(self._eu_new)
+            self._u_ok = True
+            self._u_live = False
         # conv1: d out1 = trunk-path gradient + skip gradient
         o.axpby(gy, gy, 1.0, d_trunk, 1.0)
         o.conv_wgrad(self.cv_conv1, x, gy, GW("conv1"), db=GB("conv1"))

@@ -116,6 +116,8 @@ class HipOps:
         self.f8 = bool(f8_critic or f8_generator)
         self.f8_generator = bool(f8_generator)
         self.f8_wgrad = os.environ.get("DG_NO_F8_WGRAD") is None     # fp8 weight gradients of the eligible critic layers (f8 mode only)
+        self.f8_gbwd = os.environ.get("DG_NO_F8_GBWD") is None       # f8_generator: also the dense blocks' data gradients on the MXFP8 kernel
+        self.f8_gwgrad = os.environ.get("DG_NO_F8_GWGRAD") is None   # ... and their weight gradients on the fp8 kernel (uniform-scale slab copies)
         assert not self.f8 or dtype == "bf16", "the fp8 conv path quantises bf16 tensors"
         self._f8_scratch = {}
         if deterministic is None:
@@ -282,7 +284,8 @@ class HipOps:
             return (self.f8 and self.f8_wgrad and cv.net == "C" and not cv.pixel_shuffle and cv.Cin % 128 == 0
                     and cv.Cout % 128 == 0 and cv.Wo % 64 == 0)
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
-        nets = ("C", "G") if (self.f8_generator and kind == "fwd") else ("C",)
+        # generator layers (net "G": the dense-block trunk): forward always in f8_generator mode, data gradients when f8_gbwd is on
+        nets = ("C", "G") if (self.f8_generator and (kind == "fwd" or self.f8_gbwd)) else ("C",)
         return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
 
     def conv_fwd(self, cv: Conv, x, w_fwd, y, xq=None, wq=None, **ep):
@@ -449,6 +452,25 @@ class HipOps:
         check(self._timed("conv_wgrad", flops, lambda: self.lib.dg_conv3x3_wgrad_dense(
             C.byref(g), n, _ptr(slab), _ptr(us), pw, pb, self._stream()), nbytes, cv0.net, f"dense{n}x{F_}@{cv0.H}"), "dg_conv3x3_wgrad_dense")
 
+    def conv_wgrad_dense_f8(self, cvs, slab_u, ex, us_u, eu, dws):
+        """conv_wgrad_dense on the fp8 kernel (dg_conv3x3_wgrad_dense_f8): ``slab_u`` / ``us_u`` = uniform-scale E4M3 copies of the
+        block's activation / adjoint slabs [N, H, W, n*F] with block exponents ``ex`` / ``eu`` (uint8 [n*F / 32]); weight gradients
+        only (bias gradients: ``colsum`` of the adjoint slices)."""
+        n, F_ = len(cvs), cvs[0].Cout
+        cv0 = cvs[0]
+        assert F_ == 128 and cv0.W % 64 == 0 and all(c.Cin == (k + 1) * F_ and c.Cout == F_ and c.stride == 1 and not c.pixel_shuffle for k, c in enumerate(cvs))
+        assert slab_u.dtype == torch.uint8 and us_u.dtype == torch.uint8 and tuple(slab_u.shape) == (cv0.N, cv0.H, cv0.W, n * F_) == tuple(us_u.shape)
+        assert ex.dtype == torch.uint8 and eu.dtype == torch.uint8 and ex.numel() == n * F_ // 32 == eu.numel() and ex.is_contiguous() and eu.is_contiguous()
+        for k in range(n):
+            assert dws[k].dtype == torch.float32 and dws[k].numel() == F_ * 9 * (k + 1) * F_ and dws[k].is_contiguous()
+        cvv = Conv(cv0.N, cv0.H, cv0.W, n * F_, n * F_, net=cv0.net)
+        g = self._geom(cvv, pix_layout(slab_u)[0], pix_layout(us_u)[0])
+        pw = (C.c_void_p * n)(*[t.data_ptr() for t in dws])
+        flops = sum(self.conv_flops(c) for c in cvs)
+        check(self._timed("conv_wgrad_f8", flops, lambda: self.lib.dg_conv3x3_wgrad_dense_f8(
+            C.byref(g), n, _ptr(slab_u), _ptr(ex), _ptr(us_u), _ptr(eu), pw, self._stream()),
+            float(slab_u.numel() + us_u.numel()), cv0.net, f"dense{n}x{F_}@{cv0.H}"), "dg_conv3x3_wgrad_dense_f8")
+
     def colsum(self, dy, db):
         """db[c] += sum over all pixels/rows of dy[..., c]; dy is NHWC (any dtype of {fp32, compute}) or 2-D."""
         assert db.dtype == torch.float32
@@ -460,6 +482,16 @@ class HipOps:
             Cc = dy.shape[-1]
         assert db.numel() >= Cc
         check(self.lib.dg_colsum(dg, _ptr(dy), rows, ld, 1, ld, Cc, _ptr(db), self._stream()), "dg_colsum")
+
+    def colsum_multi(self, dy, dbs):
+        """dbs[k][c] += sum over pixels of dy[..., k * (C / n) + c] for the n equal channel segments of dy, one pass (dg_colsum_multi)."""
+        self._act(dy)
+        n, Cc = len(dbs), dy.shape[-1]
+        assert Cc % n == 0 and all(d.dtype == torch.float32 and d.numel() >= Cc // n for d in dbs)
+        ld, rows = pix_layout(dy)
+        pb = (C.c_void_p * n)(*[t.data_ptr() for t in dbs])
+        check(self._timed("ew_colsum", 0.0, lambda: self.lib.dg_colsum_multi(self.dg, _ptr(dy), rows, ld, Cc, n, pb, self._stream()),
+                          float(dy.numel() * dy.element_size()), "G"), "dg_colsum_multi")
 
     def colsum_ps(self, dy, db):
         """Bias gradient of a pixel-shuffle conv: dy is stored shuffled [N,2H,2W,F]; db has 4F entries

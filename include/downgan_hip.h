@@ -139,7 +139,10 @@ int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, const void* d
  * weight-gradient of nn.Conv2d (wasserstein.py:52,80) and, with (x:=tangent, dy:=adjoint), the
  * double-backward term of the gradient penalty (wasserstein.py:100-117 under :52). */
 int dg_conv3x3_wgrad(const dg_conv_geom* g, const void* x, const void* dy, float* dw, float* db,
-                     void* stream); /* Weight and bias gradients of ALL convs of a dense block (generator.py:14-41) in one launch.  Conv k = 1..nconv reads channels
+                     void* stream);
+  /* db (optional): bias gradient += sum_pixels dy */
+
+/* Weight and bias gradients of ALL convs of a dense block (generator.py:14-41) in one launch.  Conv k = 1..nconv reads channels
  * [0, k*128) of the block's activation slab x [N,H,W,nconv*128] and its output adjoint is channels [(k-1)*128, k*128) of the
  * adjoint slab dy; dw[k-1] ([128][9][k*128] fp32) and db[k-1] ([128] fp32, db or any entry may be NULL) are accumulated into.
  * g: Cin = Cout = nconv*128, stride 1, ldx / ldy = pixel strides of the two slabs; bf16; W % 32 == 0. */
@@ -154,13 +157,24 @@ int dg_conv3x3_wgrad_dense(const dg_conv_geom* g, int nconv, const void* x, cons
  * multiples of 128, W a multiple of 64, no pixel shuffle; anything else returns DG_ERR_BAD_SHAPE (callers keep the bf16 kernel). */
 int dg_conv3x3_wgrad_f8(const dg_conv_geom* g, const void* xq, const void* ex, const void* dyq, const void* ey, float* dw,
                         void* stream);
-  /* db (optional): bias gradient += sum_pixels dy */
+
+/* dg_conv3x3_wgrad_dense on the fp8 kernel (autograd of DoWnGAN/networks/generator.py:24-41 under GAN/wasserstein.py:80 in fp8 mode):
+ * xq / dyq = uniform-scale E4M3 copies of the block's activation and adjoint slabs [N,H,W,nconv*128] (pixel strides g->ldx / g->ldy
+ * in bytes), ex / ey = their nconv*4 block exponents (as dg_conv3x3_wgrad_f8); dw[k-1] ([128][9][k*128] fp32) accumulated into.
+ * Weight gradients only: the bias gradients are column sums of the adjoint slab (dg_colsum).  Stride 1, W a multiple of 64. */
+int dg_conv3x3_wgrad_dense_f8(const dg_conv_geom* g, int nconv, const void* xq, const void* ex, const void* dyq, const void* ey,
+                              float* const* dw, void* stream);
 
 /* db[c] (fp32) += sum over rows of dy[row, c]  (bias gradient of a conv or Linear).  Row r is at
  * element offset (r / rows_inner)*ld_outer + (r % rows_inner)*ld, so one sub-position of a
  * pixel-shuffled tensor can be reduced (rows_outer x rows_inner rows in total). */
 int dg_colsum(int dtype, const void* dy, int64_t rows_outer, int64_t ld_outer, int64_t rows_inner,
               int64_t ld, int C, float* db, void* stream);
+
+/* One pass over a wide tensor, nseg (<= 8) destinations: db[k][c] (fp32) += sum over rows of dy[row, k*(C/nseg) + c]; rows of `ld`
+ * elements.  The five bias gradients of a dense block (generator.py:24-41) from its adjoint slab when the weight gradients run on
+ * dg_conv3x3_wgrad_dense_f8 (the bf16 dense launch sums them itself). */
+int dg_colsum_multi(int dtype, const void* dy, int64_t rows, int64_t ld, int C, int nseg, float* const* db, void* stream);
 
 /* Launches one gather-GEMM descriptor (what dg_conv3x3_fwd / _dgrad call after planning). */
 int dg_gather_gemm(const dg_gg_desc* d, const dg_epilogue* ep, const void* x, const void* w, void* y,

@@ -193,6 +193,14 @@ class EmuOps:
         assert cv.Cin % 128 == 0 and cv.Cout % 128 == 0 and cv.Wo % 64 == 0 and not cv.pixel_shuffle
         self.conv_wgrad(cv, self.uq_dequant(xq, ex), self.uq_dequant(dyq, ey), dw)
 
+    def conv_wgrad_dense_f8(self, cvs, slab_u, ex, us_u, eu, dws):
+        """dg_conv3x3_wgrad_dense_f8: the dense block's five weight gradients from the uniform-scale copies of its slabs."""
+        F_ = cvs[0].Cout
+        assert cvs[0].W % 64 == 0 and F_ == 128
+        x, u = self.uq_dequant(slab_u, ex), self.uq_dequant(us_u, eu)
+        for k, c in enumerate(cvs):
+            self.conv_wgrad(c, x[..., :(k + 1) * F_], u[..., k * F_:(k + 1) * F_], dws[k])
+
     # ---- MXFP8 (csrc/quant.hip): OCP E4M3 elements, one E8M0 scale per block of 32 consecutive channels (OCP MX layout);
     # scale = 2^(floor(log2 amax) - 8)
     @staticmethod
@@ -219,13 +227,16 @@ class EmuOps:
         return q, scales
 
     f8_wgrad = True
+    f8_gbwd = True
+    f8_gwgrad = True
 
     def f8_eligible(self, cv, kind):
         if kind == "wgrad":
             return (self.f8 and self.f8_wgrad and cv.net == "C" and not cv.pixel_shuffle and cv.Cin % 128 == 0
                     and cv.Cout % 128 == 0 and cv.Wo % 64 == 0)
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
-        nets = ("C", "G") if (self.f8_generator and kind == "fwd") else ("C",)
+        # generator layers (net "G": the dense-block trunk): forward always in f8_generator mode, data gradients when f8_gbwd is on
+        nets = ("C", "G") if (self.f8_generator and (kind == "fwd" or self.f8_gbwd)) else ("C",)
         return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
 
     @staticmethod
@@ -290,6 +301,11 @@ class EmuOps:
     def colsum(self, dy, db):
         Cc = dy.shape[-1]
         db[:Cc] += dy.float().reshape(-1, Cc).sum(0)
+
+    def colsum_multi(self, dy, dbs):
+        seg = dy.shape[-1] // len(dbs)
+        for k, db in enumerate(dbs):
+            self.colsum(dy[..., k * seg:(k + 1) * seg], db)
 
     def colsum_ps(self, dy, db):
         f = dy.shape[-1]

@@ -88,6 +88,97 @@ def test_generator_fp8_trunk_on_emulated_ops():
     assert float((outs[True][0] - outs[False][0]).norm() / outs[False][0].norm()) < 0.1
 
 
+def test_generator_fp8_data_gradients_on_emulated_ops():
+    """f8_generator with f8_gbwd: the dense blocks' data gradients (autograd of generator.py:24-41) read the adjoint slab's MXFP8
+    form -- slices written by the producing epilogues (activation mask + copy, residual + copy) and one quantiser call per RRDB
+    -- and the quantised virtual packs; parameter gradients stay close to the ones of the bf16 data gradients, and the layers
+    outside the trunk's backward chain (up-sampling tail, conv3.*) are bit-identical."""
+    from downgan_amd import synthetic
+    from downgan_amd.engine import NativeGenerator
+    from downgan_amd.layout import nchw_to_nhwc_padded
+    torch.set_num_threads(4)
+    B, S, F_, cin, nrb = 1, 8, 128, 2, 1
+    coarse, _ = synthetic.tiles(B, cin, S)
+    xc = nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.float32)
+    grads, calls = {}, {}
+    for gb in (False, True):
+        ops = EmuOps("f32", f8_generator=True)
+        ops.f8_gbwd = gb
+        seen = calls[gb] = []
+        real = ops.conv_dgrad
+        ops.conv_dgrad = lambda cv, dy, w, dx, _r=real, _s=seen, **kw: (_s.append((cv.net, cv.Cout, kw.get("xq") is not None, kw.get("out_q") is not None)),
+                                                                         _r(cv, dy, w, dx, **kw))[1]
+        G = NativeGenerator(ops, F_, cin, B, S, num_res_blocks=nrb, num_upsample=1)
+        assert G.f8 and G.f8_bwd == gb
+        G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb, num_upsample=1))
+        fake = G.forward(xc, save=True)
+        dfake = torch.randn(fake.shape, generator=torch.Generator().manual_seed(3)) * (torch.arange(fake.shape[-1]) < 2)
+        G.P.zero_grad()
+        G.backward(xc, dfake)
+        grads[gb] = G.grad_dict()
+    # 3 dense blocks x 5 virtual convs read producer-written forms; all but the RRDB's first block's last one write the next form
+    trunk = [c for c in calls[True] if c[0] == "G" and c[2]]
+    assert len(trunk) == 15 and sum(c[3] for c in trunk) == 14, trunk
+    assert not any(c[2] or c[3] for c in calls[False])
+    for name in ("conv3.2.weight", "conv3.0.weight", "upsampling.0.weight", "conv2.weight"):
+        assert torch.equal(grads[False][name], grads[True][name]), name               # upstream of the dense blocks' backward
+    worst = 0.0
+    for name, ga in grads[False].items():
+        gb_ = grads[True][name]
+        if name.startswith(("res_blocks", "conv1")):
+            d = float((ga - gb_).norm() / ga.norm())
+            assert 0 < d < 0.12, (name, d)                                             # went through fp8 and stayed close
+            worst = max(worst, d)
+    assert worst > 1e-3
+
+
+def test_generator_fp8_weight_gradients_after_the_first_iteration():
+    """f8_gwgrad: the dense blocks' weight gradients (autograd of generator.py:24-41) from uniform-scale copies of the activation and
+    adjoint slabs.  The first generator iteration has no exponents yet: bf16 kernel, gradients identical to the mode without; from
+    the second on dg_conv3x3_wgrad_dense_f8 runs once per dense block, bias gradients come from column sums of the bf16 adjoint
+    (identical), weight gradients stay close."""
+    from downgan_amd import synthetic
+    from downgan_amd.engine import NativeGenerator
+    from downgan_amd.layout import nchw_to_nhwc_padded
+    torch.set_num_threads(4)
+    B, S, F_, cin, nrb = 1, 64, 128, 2, 1           # rows of 64 pixels: the fp8 kernel's K step
+    coarse, _ = synthetic.tiles(B, cin, S)
+    xc = nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.float32)
+    res = {}
+    for wg in (False, True):
+        ops = EmuOps("f32", f8_generator=True)
+        ops.f8_wgrad = True
+        ops.f8_gwgrad = wg
+        calls = []
+        real = ops.conv_wgrad_dense_f8
+        ops.conv_wgrad_dense_f8 = lambda *a, _r=real: (calls.append(1), _r(*a))[1]
+        G = NativeGenerator(ops, F_, cin, B, S, num_res_blocks=nrb, num_upsample=0)
+        assert G.f8_bwd and G.f8_wg == wg
+        G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb, num_upsample=0))
+        per_iter = []
+        for it in range(2):
+            fake = G.forward(xc, save=True)
+            dfake = torch.randn(fake.shape, generator=torch.Generator().manual_seed(3 + it)) * (torch.arange(fake.shape[-1]) < 2)
+            G.P.zero_grad()
+            n0 = len(calls)
+            G.backward(xc, dfake)
+            per_iter.append((len(calls) - n0, G.grad_dict()))
+        res[wg] = per_iter
+    assert [n for n, _ in res[False]] == [0, 0] and [n for n, _ in res[True]] == [0, 3]
+    for name, g0 in res[False][0][1].items():
+        assert torch.equal(g0, res[True][0][1][name]), name                          # first iteration: no exponents yet
+    worst = 0.0
+    for name, ga in res[False][1][1].items():
+        gb = res[True][1][1][name]
+        if name.startswith("res_blocks") and name.endswith("weight"):
+            d = float((ga - gb).norm() / ga.norm())
+            assert 0 < d < 0.08, (name, d)
+            worst = max(worst, d)
+        else:                                                                        # biases (column sums of the bf16 adjoint), other layers
+            assert torch.allclose(ga, gb, rtol=1e-5, atol=1e-7), name
+    assert worst > 1e-3
+
+
 def test_uniform_scale_copy_and_block_exponents():
     """The operand format of the fp8 weight gradient (oracle/emu_ops.py::uq_quant, csrc/gg_common.h epi64_pixel f_u): E4M3 with one
     exponent per 32-channel block of the whole tensor; block_exp_max = the largest MXFP8 block exponent + margin."""

@@ -203,7 +203,8 @@ def test_fused_mxfp8_output_equals_quantised_store(case):
 
 def test_fp8_generator_trunk_matches_emulation():
     """HipOps(f8_generator=True): the generator's dense-block trunk forward on the fp8 kernel with slab-sliced fp8 forms
-    (strided scale rows, epilogue-written slices) against the emulated engine; backward still runs from the bf16 slabs."""
+    (strided scale rows, epilogue-written slices) against the emulated engine, and its backward (fp8 data gradients of the dense
+    blocks, bf16 weight gradients) against the emulated backward."""
     from downgan_amd import synthetic
     from downgan_amd.engine import NativeGenerator
     from downgan_amd.layout import nchw_to_nhwc_padded
@@ -224,10 +225,131 @@ def test_fp8_generator_trunk_matches_emulation():
         err = float((got - ref)[..., :2].abs().max()) / max(1e-6, float(ref[..., :2].abs().max()))
         assert err < 3e-2, (save, err)
     close(G.trunk, emu.trunk, "fp8 trunk", tol=3e-2)
-    dfake = torch.randn(G.fake.shape).to(torch.bfloat16).cuda()
+    # backward: the dense blocks' data gradients on the MXFP8 kernel too (f8_gbwd: adjoint-slab forms written by the epilogues
+    # with the activation mask / the residual, quantised virtual packs), weight gradients bf16 from the saved slabs
+    assert G.f8_bwd and emu.f8_bwd
+    dfake = (torch.randn(G.fake.shape, generator=torch.Generator().manual_seed(5)) * (torch.arange(G.fake.shape[-1]) < 2)).to(torch.bfloat16)
+    emu.P.zero_grad()
+    emu.backward(nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.bfloat16), dfake)
     G.P.zero_grad()
-    G.backward(xc, dfake)                                                       # bf16 backward from the saved slabs
-    assert float(G.P.g.abs().sum()) > 0 and bool(torch.isfinite(G.P.g).all())
+    G.backward(xc, dfake.cuda())
+    assert bool(torch.isfinite(G.P.g).all())
+    ge, gg = emu.grad_dict(), G.grad_dict()
+    # Yardsticks (tools/f8_gbwd_check.py on one box): the two engines' FORWARD states already differ by E4M3 code flips, which a
+    # random dfake turns into 0.05-0.14 of rel-l2 on these gradients with bf16 data gradients too (conv3.0 0.05, dense blocks
+    # 0.11-0.14); the fp8 data gradients add <= 0.015 to that, and the format's own error (fp8 vs bf16 data gradients on ONE
+    # engine) is 0.042-0.063 on both engines alike.  So: the same format error on both sides, and nothing beyond the yardstick.
+    ops16 = HipOps("bf16", f8_generator=True); ops16.f8_gbwd = False
+    G16 = NativeGenerator(ops16, F_, cin, B, S, num_res_blocks=nrb)
+    assert G16.f8 and not G16.f8_bwd
+    G16.load_state_dict(pg)
+    G16.forward(xc, save=True)
+    G16.P.zero_grad(); G16.backward(xc, dfake.cuda())
+    emu16_ops = EmuOps("bf16", f8_generator=True); emu16_ops.f8_gbwd = False
+    emu16 = NativeGenerator(emu16_ops, F_, cin, B, S, num_res_blocks=nrb)
+    emu16.load_state_dict(pg)
+    xe = nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.bfloat16)
+    emu16.forward(xe, save=True)
+    emu16.P.zero_grad(); emu16.backward(xe, dfake)
+    g16, e16 = G16.grad_dict(), emu16.grad_dict()
+    rel = lambda a, b: float((a.float().cpu() - b.float().cpu()).norm() / max(1e-12, float(a.float().norm())))
+    for name, a in ge.items():
+        if not name.endswith("weight"):
+            continue
+        d8, d16 = rel(a, gg[name]), rel(e16[name], g16[name])
+        assert d8 <= d16 + 0.03, (name, d8, d16)                                 # hip vs emulation: no worse than with bf16 data gradients
+        if name.startswith("res_blocks"):
+            fe, fh = rel(e16[name], a), rel(g16[name], gg[name])                 # the format's error, emulated / native
+            assert 0.02 < fh < 0.09 and abs(fh - fe) < 0.25 * fe, (name, fe, fh)
+        elif not name.startswith("conv1"):
+            assert rel(g16[name], gg[name]) < 1e-5, name                          # upstream of the dense blocks' backward: untouched (atomic order only)
+
+
+def test_fp8_generator_weight_gradients_second_iteration():
+    """f8_gwgrad on the native engine: the first generator iteration collects the slabs' block exponents (bf16 weight-gradient kernel),
+    the second writes the uniform-scale copies in the conv epilogues (forward: bias + LeakyReLU / residuals + copies; backward:
+    activation mask / residual + copies) and runs dg_conv3x3_wgrad_dense_f8.  Against the same engine with f8_gwgrad off: bias
+    gradients and everything outside the dense blocks agree to atomic order, weight gradients to the format's error -- the same
+    error the emulated engine shows (tests/test_fp8_cpu.py)."""
+    from downgan_amd import synthetic
+    from downgan_amd.engine import NativeGenerator
+    B, S, F_, cin, nrb = 2, 64, 128, 2, 1
+    pg = synthetic.generator_params(F_, cin, 2, nrb, num_upsample=0)
+    coarse, _ = synthetic.tiles(B, cin, S)
+    res = {}
+    for wg in (False, True):
+        ops = HipOps("bf16", f8_generator=True)
+        ops.f8_gwgrad = wg
+        G = NativeGenerator(ops, F_, cin, B, S, num_res_blocks=nrb, num_upsample=0)
+        assert G.f8_bwd and G.f8_wg == wg
+        G.load_state_dict(pg)
+        xc = ops.zeros(B, S, S, 16); ops.nchw_to_nhwc(torch.from_numpy(coarse).cuda(), xc)
+        out = []
+        for it in range(2):
+            fake = G.forward(xc, save=True)
+            dfake = (torch.randn(fake.shape, generator=torch.Generator().manual_seed(3 + it)) * (torch.arange(fake.shape[-1]) < 2)).to(torch.bfloat16).cuda()
+            G.P.zero_grad()
+            G.backward(xc, dfake)
+            out.append({k: v.float().cpu() for k, v in G.grad_dict().items()})
+        res[wg] = out
+        assert wg == bool(G._u_ok)
+    rel = lambda a, b: float((a - b).norm() / max(1e-20, float(a.norm())))
+    for name, g0 in res[False][0].items():
+        assert rel(g0, res[True][0][name]) < 1e-5, name                              # first iteration: bf16 kernel in both
+    worst = 0.0
+    for name, ga in res[False][1].items():
+        d = rel(ga, res[True][1][name])
+        if name.startswith("res_blocks") and name.endswith("weight"):
+            assert 1e-4 < d < 0.08, (name, d)
+            worst = max(worst, d)
+        else:
+            assert d < 1e-4, (name, d)
+    assert worst > 1e-3
+
+
+def test_dense_block_data_gradient_on_slab_slices_fp8():
+    """One virtual data gradient of a dense block (engine.py NativeGenerator.backward; autograd of generator.py:24-41) on the MXFP8
+    kernel: the adjoint operand is a channel slice [kF, 5F) of the slab's fp8 form with strided scale rows, the epilogue applies
+    the ACTIVATION mask of a slab slice and writes the bf16 slice plus its MXFP8 copy into slice k-1 (straight-line instance 288);
+    and the block's last one: residual + copy into another slab's slice (264).  Against the emulation on the same quantised
+    operands (accumulation order only) and, for the copies, dg_quant_mxfp8 of the stored slice bit for bit."""
+    B, S, F_ = 2, 24, 128
+    g = torch.Generator().manual_seed(77)
+    hip, emu = HipOps("bf16", f8_generator=True), EmuOps("bf16", f8_generator=True)
+    us = (torch.randn(B, S, S, 5 * F_, generator=g) * 1e-3 * torch.logspace(-1, 1, 5 * F_)).to(torch.bfloat16)
+    slab = torch.randn(B, S, S, 5 * F_, generator=g).to(torch.bfloat16)
+    usd = us.cuda()
+    usq = (torch.zeros(B, S, S, 5 * F_, dtype=torch.uint8).cuda(), torch.zeros(B, S, S, 5 * F_ // 32, dtype=torch.uint8).cuda())
+    hip.quant_mxfp8(usd, *usq)
+    usq_e = tuple(t.cpu().clone() for t in usq)
+    for k in (3, 0):
+        cv = Conv(B, S, S, F_, (5 - k) * F_, net="G")
+        assert hip.f8_eligible(cv, "dgrad")
+        wd = (torch.randn(F_ * 9 * (5 - k) * F_, generator=g) * 0.05).to(torch.bfloat16)
+        wq = hip.quant_mxfp8(wd.cuda().view(F_ * 9, (5 - k) * F_))
+        wq_e = tuple(t.cpu() for t in wq)
+        sl = lambda t, c0, c1: (t[0][..., c0:c1], t[1][..., c0 // 32:c1 // 32])
+        if k:       # u_k = LeakyReLU'(b_k) * sum ...: slice k-1 of the SAME slab
+            ep = lambda dev: dict(mask=(slab.cuda() if dev else slab)[..., k * F_:(k + 1) * F_], mask_slope=0.2)
+            out_h, out_e = usd[..., (k - 1) * F_:k * F_], us[..., (k - 1) * F_:k * F_]
+            oq_h, oq_e = sl(usq, (k - 1) * F_, k * F_), sl(usq_e, (k - 1) * F_, k * F_)
+        else:       # d x_drb: residual of the block's own u5, stored into another slab's top slice
+            nxt_h = torch.zeros(B, S, S, 5 * F_, dtype=torch.bfloat16).cuda(); nxt_e = torch.zeros(B, S, S, 5 * F_, dtype=torch.bfloat16)
+            nq_h = (torch.zeros(B, S, S, 5 * F_, dtype=torch.uint8).cuda(), torch.zeros(B, S, S, 5 * F_ // 32, dtype=torch.uint8).cuda())
+            nq_e = tuple(t.cpu().clone() for t in nq_h)
+            ep = lambda dev: dict(r1=(usd if dev else us)[..., 4 * F_:], s1=0.2)
+            out_h, out_e = nxt_h[..., 4 * F_:], nxt_e[..., 4 * F_:]
+            oq_h, oq_e = sl(nq_h, 4 * F_, 5 * F_), sl(nq_e, 4 * F_, 5 * F_)
+        emu.conv_dgrad(cv, us[..., k * F_:], wd, out_e, xq=sl(usq_e, k * F_, 5 * F_), wq=wq_e, out_q=oq_e, **ep(False))
+        hip.conv_dgrad(cv, usd[..., k * F_:], wd.cuda(), out_h, xq=sl(usq, k * F_, 5 * F_), wq=wq, out_q=oq_h, **ep(True))
+        assert hip.lib.dg_last_conv_kernels() == 32
+        a, b = out_h.float().cpu(), out_e.float()
+        assert float(b.abs().max()) > 0 and float((a - b).abs().max()) <= 1.6e-2 * float(b.abs().max()), (k, float((a - b).abs().max()), float(b.abs().max()))
+        q_ref, s_ref = hip.quant_mxfp8(out_h.contiguous())
+        assert torch.equal(oq_h[1].contiguous(), s_ref), (k, int((oq_h[1] != s_ref).sum()))
+        assert torch.equal(oq_h[0].contiguous(), q_ref), (k, int((oq_h[0] != q_ref).sum()))
+        if k:       # the rest of the slab's form is untouched, and the new slice feeds the next data gradient
+            us = usd.cpu(); usq_e = tuple(t.cpu().clone() for t in usq)
 
 
 def test_mirrors_accept_fp8_dtype():
@@ -297,6 +419,64 @@ def test_wgrad_f8_uniform_scales(cfg):
         with pytest.raises((RuntimeError, AssertionError)):
             hip.conv_wgrad_f8(bad, torch.zeros(bad.N, bad.H, bad.W, bad.Cin, dtype=torch.uint8).cuda(), torch.zeros(max(bad.Cin // 32, 1), dtype=torch.uint8).cuda(),
                               torch.zeros(bad.N, bad.Ho, bad.Wo, co, dtype=torch.uint8).cuda(), ey.cuda(), torch.zeros(co * 9 * bad.Cin).cuda())
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 64, 5), (1, 9, 128, 5), (3, 7, 64, 3)])
+def test_wgrad_dense_f8_uniform_scales(cfg):
+    """dg_conv3x3_wgrad_dense_f8: the weight gradients of all convs of a dense block (autograd of DoWnGAN/networks/generator.py:24-41;
+    conv k reads slab channels [0, k * 128), its adjoint is slice k - 1 of the adjoint slab) in one launch of the fp8 kernel, against
+    the emulation's fp32 weight gradients of the dequantised slabs (summation order only); accumulates; deterministic mode agrees."""
+    from oracle.emu_ops import EmuOps
+    N, H, W, n = cfg
+    F_ = 128
+    g = torch.Generator().manual_seed(sum(cfg))
+    hip, emu = HipOps("bf16"), EmuOps("f32")
+    cvs = [Conv(N, H, W, k * F_, F_, net="G") for k in range(1, n + 1)]
+    slab = torch.randn(N, H, W, n * F_, generator=g) * torch.logspace(-1, 1, n * F_)
+    us = torch.randn(N, H, W, n * F_, generator=g) * 1e-3 * torch.logspace(0, 1, n * F_)
+    def exps(t):
+        am = t.abs().reshape(-1, t.shape[-1] // 32, 32).amax(dim=(0, 2))
+        return (torch.floor(torch.log2(am)) - 8 + 127 + 1).to(torch.uint8)
+    ex, eu = exps(slab), exps(us)
+    sq, _ = _quant_uniform(slab, ex)
+    uq, _ = _quant_uniform(us, eu)
+    refs = [torch.randn(F_ * 9 * k * F_, generator=g) * 1e-3 for k in range(1, n + 1)]
+    dws = [r.clone().cuda() for r in refs]
+    emu.conv_wgrad_dense_f8(cvs, sq, ex, uq, eu, refs)
+    hip.conv_wgrad_dense_f8(cvs, sq.cuda(), ex.cuda(), uq.cuda(), eu.cuda(), dws)
+    for k in range(n):
+        scale = float(refs[k].abs().max())
+        err = float((dws[k].cpu() - refs[k]).abs().max())
+        assert err <= 1e-5 * scale * 8, (cfg, k, err, scale)
+    # the block's bias gradients in this mode: one pass of column sums over the bf16 adjoint slab (dg_colsum_multi), accumulated
+    usb = us.to(torch.bfloat16)
+    db0 = [torch.randn(F_, generator=g) for _ in range(n)]
+    dbs = [t.clone().cuda() for t in db0]
+    hip.colsum_multi(usb.cuda(), dbs)
+    for k in range(n):
+        ref = db0[k] + usb[..., k * F_:(k + 1) * F_].float().reshape(-1, F_).sum(0)
+        assert float((dbs[k].cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (cfg, k)
+    det = HipOps("bf16", deterministic=True)
+    try:
+        d1 = [torch.zeros(F_).cuda() for _ in range(n)]; d2 = [torch.zeros(F_).cuda() for _ in range(n)]
+        det.colsum_multi(usb.cuda(), d1); det.colsum_multi(usb.cuda(), d2)
+        assert all(torch.equal(a, b) for a, b in zip(d1, d2))
+        assert all(float((d1[k].cpu() - usb[..., k * F_:(k + 1) * F_].float().reshape(-1, F_).sum(0)).abs().max()) <= 1e-4 for k in range(n))
+        runs = []
+        for _ in range(2):
+            d2 = [torch.zeros_like(r).cuda() for r in refs]
+            det.conv_wgrad_dense_f8(cvs, sq.cuda(), ex.cuda(), uq.cuda(), eu.cuda(), d2)
+            runs.append(torch.cat([t.cpu() for t in d2]))
+        assert torch.equal(runs[0], runs[1])
+        z = [torch.zeros_like(r) for r in refs]
+        emu.conv_wgrad_dense_f8(cvs, sq, ex, uq, eu, z)
+        zc = torch.cat(z)
+        assert float((runs[0] - zc).abs().max()) <= 1e-5 * float(zc.abs().max()) * 8
+    finally:
+        det.close()
+    with pytest.raises((RuntimeError, AssertionError)):                       # rows that are not a multiple of 64 pixels: refused
+        bad = [Conv(N, H, 32, k * F_, F_) for k in range(1, n + 1)]
+        hip.conv_wgrad_dense_f8(bad, torch.zeros(N, H, 32, n * F_, dtype=torch.uint8).cuda(), ex.cuda(), torch.zeros(N, H, 32, n * F_, dtype=torch.uint8).cuda(), eu.cuda(), dws)
 
 
 @pytest.mark.parametrize("case", ["fp8_s2_forward", "fp8_s2_dgrad_classes", "fp8_s1_forward_mask_bits", "bf16_halo", "general_epilogue"])
