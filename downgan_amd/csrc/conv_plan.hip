@@ -71,9 +71,9 @@ static int gg_launch(GGArgs& a, int dtype, int N, hipStream_t st) {
 
 // fp8 launches: only the shapes the four-wave halo kernel takes (the critic's wide layers); everything else is refused
 static int gg_launch_f8(GGArgs& a, const F8Args& f, int N, hipStream_t st) {
-  if (a.cch % 8 || a.Nout <= 64 || a.Hg < 8 || a.Wg < 8 || a.src_ps || a.dst_ps) return DG_ERR_BAD_SHAPE;
+  if (a.cch % 8 || a.Nout <= 64 || a.Hg < 8 || a.Wg < 8 || a.src_ps) return DG_ERR_BAD_SHAPE;    // (a pixel-shuffled DESTINATION is the epilogue's business)
   if (a.sy_mul == 1 && a.sx_mul == 1 && a.Hs == a.Hg && a.Ws == a.Wg) return gg_launch_halo_f8(a, f, N, false, 4, st);
-  if (a.sy_mul == 2 && a.sx_mul == 2 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1) {
+  if (a.sy_mul == 2 && a.sx_mul == 2 && a.Hs == 2 * a.Hg && a.Ws == 2 * a.Wg && a.dy_mul == 1 && a.dx_mul == 1 && !a.dst_ps) {
     GGArgs b = a;
     if (gg_regroup_taps_by_plane(b)) {
       return gg_launch_halo_f8(b, f, N, true, b.Nout % 256 == 0 ? 8 : 4, st);
@@ -121,12 +121,16 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     if (a.no_y && (!a.out_q || a.accumulate)) return DG_ERR_BAD_ARG;          // (the first-layer launcher checks its own shapes)
     // the MXFP8 copy is written by the 64-channel wave-tile epilogues of bf16 launches: same shape rules as the bit masks
     if ((a.out_q != nullptr) != (a.out_qs != nullptr)) return DG_ERR_BAD_ARG;
-    if (a.out_q && (d->dtype != DG_BF16 || d->Nout < 128 || d->Nout % 64 || d->dst_ps)) return DG_ERR_BAD_SHAPE;
-    a.ldqs = ep->ldqs > 0 ? (int)ep->ldqs : d->Nout / 32;
+    if (a.out_q && (d->dtype != DG_BF16 || d->Nout < 128 || d->Nout % 64)) return DG_ERR_BAD_SHAPE;
+    // scale bytes per DESTINATION pixel: a pixel-shuffled output has Nout / 4 channels per pixel (the 32-channel blocks of a channel
+    // quarter stay together: quarters of a multiple of 32 channels)
+    const int cdst = d->dst_ps ? d->Nout / 4 : d->Nout;
+    if (a.out_q && d->dst_ps && (cdst % 32 || a.out_u || a.mask_bits || a.out_bits)) return DG_ERR_BAD_SHAPE;
+    a.ldqs = ep->ldqs > 0 ? (int)ep->ldqs : cdst / 32;
     a.qs_shift = 0;
-    if (a.out_q && a.ldqs != d->Nout / 32) {        // strided scale rows: the kernel splits the mask-word index by a shift
-      const int n16 = d->Nout / 16;
-      if ((n16 & (n16 - 1)) || a.ldqs < d->Nout / 32) return DG_ERR_BAD_SHAPE;
+    if (a.out_q && (a.ldqs != cdst / 32 || d->dst_ps)) {   // strided scale rows / shuffled pixels: the kernel splits a (pixel, 16-channel group) index by a shift
+      const int n16 = cdst / 16;
+      if ((n16 & (n16 - 1)) || a.ldqs < cdst / 32) return DG_ERR_BAD_SHAPE;
       while ((1 << a.qs_shift) < n16) ++a.qs_shift;
     }
     // bit masks need 64-channel wave tiles (Nout >= 128 selects them in every dispatch path) and plain destinations
@@ -261,7 +265,7 @@ extern "C" int dg_conv3x3_dgrad(const dg_conv_geom* g, const dg_epilogue* ep, co
 
 // MXFP8 operands (csrc/quant.hip), bf16 output / epilogue tensors.  q->ldxq replaces the source's pixel stride of `g`.
 extern "C" int dg_conv3x3_fwd_f8(const dg_conv_geom* g, const dg_epilogue* ep, const dg_f8_operands* q, void* y, void* stream) {
-  if (!q || !g || g->dtype != DG_BF16 || g->pixel_shuffle || g->Cin % 128) return DG_ERR_BAD_SHAPE;
+  if (!q || !g || g->dtype != DG_BF16 || g->Cin % 128) return DG_ERR_BAD_SHAPE;       // (pixel-shuffled OUTPUT: the common epilogue's)
   dg_gg_desc d[4];
   g_last_kinds = 0;
   int n = dg_conv3x3_plan(g, 0, d);

@@ -263,8 +263,8 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
       __builtin_amdgcn_raw_buffer_store_b128(qv, R.rq, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
       const bool low_half = ((threadIdx.x >> 4) & 1) == 0;
       unsigned offqs = boff >> 2;                                   // dense scale rows: (rel * Nout + channel) / 32
-      if (a.ldqs != (a.Nout >> 5)) {                                // a channel slice of a wider tensor (dense-block slab)
-        const unsigned w16 = boff >> 1;                             // rel * (Nout / 16) + channel / 16, Nout / 16 a power of two
+      if (a.qs_shift) {                                             // a channel slice of a wider tensor (dense-block slab) / a pixel-shuffled output
+        const unsigned w16 = boff >> 1;                             // pixel * (C / 16) + channel / 16, C / 16 a power of two (C = channels per destination pixel)
         offqs = (w16 >> a.qs_shift) * (unsigned)a.ldqs + ((w16 & ((1u << a.qs_shift) - 1u)) >> 1);
       }
       __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, R.rqs, (low_half && boff != DG_OOB_OFF) ? offqs : DG_OOB_OFF, 0, 0);
@@ -337,7 +337,8 @@ __device__ __forceinline__ void gg_epilogue(const GGArgs& a, f32x4_t (&acc)[WC /
       epi64_pixel<T, LEAN>(a, R, acc[0][i], acc[1][i], acc[2][i], acc[3][i], bias,
                            ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
                            ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
-                           ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i], a.mask && cb16 >= a.mask_c0, nullptr, inv_u);
+                           ok ? (unsigned)((a.dst_ps ? pix * (a.cps_dst >> 4) + (cc0 >> 4) : rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[i],
+                           a.mask && cb16 >= a.mask_c0, nullptr, inv_u);
     }
     return;
   }
@@ -529,7 +530,9 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       epi64_pixel<T, (F >= 0), FE>(a, R, acc[4 * h][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i], bias,
                             ok ? (unsigned)((pix * R.ldy + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ld1 + cc0) * ES) : DG_OOB_OFF,
                             ok ? (unsigned)((pix * R.ld2 + cc0) * ES) : DG_OOB_OFF, ok ? (unsigned)((pix * R.ldm + cc0) * ES) : DG_OOB_OFF,
-                            ok ? (unsigned)((rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[h][i], a.mask && cb16 >= a.mask_c0, nullptr, inv_u);
+                            // (pixel-shuffled output: no bit masks; the MXFP8 scale byte's (destination pixel, 16-channel group) index)
+                            ok ? (unsigned)((a.dst_ps ? pix * (a.cps_dst >> 4) + (cc0 >> 4) : rel * ldb + bidx) * 2) : DG_OOB_OFF, mbv[h][i],
+                            a.mask && cb16 >= a.mask_c0, nullptr, inv_u);
     }
   }
   };
@@ -564,6 +567,7 @@ __device__ __forceinline__ void halo_epilogue(const GGArgs& a, f32x4_t (&acc)[4 
       case 261: run(std::integral_constant<int, 261>{}, htag); break;  // fp8 mode: LeakyReLU + out_bits + MXFP8 copy (critic forward)
       case 2306: run(std::integral_constant<int, 2306>{}, htag); break; // ... + the uniform-scale copy for the fp8 weight gradient (258 + 2048)
       case 2309: run(std::integral_constant<int, 2309>{}, htag); break; // (261 + 2048)
+      case 4353: run(std::integral_constant<int, 4353>{}, htag); break; // 257 without the bf16 store (up-sampling convs of a forward nobody differentiates)
       case 4354: run(std::integral_constant<int, 4354>{}, htag); break; // 258 / 261 / 2306 / 2309 without the bf16 store (+ 4096: dg_epilogue.skip_y)
       case 4357: run(std::integral_constant<int, 4357>{}, htag); break;
       case 6402: run(std::integral_constant<int, 6402>{}, htag); break;

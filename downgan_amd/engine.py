@@ -630,9 +630,9 @@ class NativeGenerator:
         self.cv_conv1 = Conv(B, S, S, self.cin_p, F_, cin_real=(channels if channels <= 2 else 0), cin_alg=channels)
         self.cv_b = [Conv(B, S, S, k * F_, F_, net="G") for k in range(1, 6)]      # net="G": fp8-eligible in f8_generator mode
         self.cv_conv2 = Conv(B, S, S, F_, F_, net="G")
-        self.cv_up = [Conv(B, S << u, S << u, F_, 4 * F_, 1, True) for u in range(num_upsample)]
+        self.cv_up = [Conv(B, S << u, S << u, F_, 4 * F_, 1, True, net="T") for u in range(num_upsample)]   # net="T": fp8-eligible forward (f8_gtail)
         hs = S << num_upsample
-        self.cv_c30 = Conv(B, hs, hs, F_, F_)
+        self.cv_c30 = Conv(B, hs, hs, F_, F_, net="T")
         self.cv_c32 = Conv(B, hs, hs, F_, self.np_p, cout_alg=n_predictands)
         # conv3.2 has <= 2 real OUTPUT channels: its backward is HBM-bound and runs on the first-layer (im2col) kernels with the
         # operand roles swapped -- data gradient = forward conv of dfake with the mirrored-tap pack, weight gradient =
@@ -671,6 +671,12 @@ class NativeGenerator:
         # backward never reads them); conv k's epilogue writes its slice of it, the next conv reads the first k+1 slices.
         self.f8 = bool(getattr(o, "f8_generator", False)) and all(o.f8_eligible(cv, "fwd") for cv in self.cv_b)
         self._qring = [(o.zeros(B, S, S, 5 * F_, dtype=torch.uint8), o.zeros(B, S, S, 5 * F_ // 32, dtype=torch.uint8)) for _ in range(4)] if self.f8 else None
+        # ... and the FORWARD of the up-sampling tail (upsampling.*, conv3.0: generator.py:69-81,88-89): every tail tensor gets an MXFP8
+        # form written by its producer's epilogue (conv2: residual + copy; up-sampling convs: the copy in SHUFFLED pixel order); a
+        # forward nobody differentiates (critic iterations) does not store the bf16 up-sampled tensors at all.  conv3.2 (2 real
+        # output channels, HBM-bound) and the tail's backward stay bf16.
+        self.f8_tail = self.f8 and all(o.f8_eligible(cv, "fwd") for cv in self.cv_up + [self.cv_c30])
+        self._tq = None
         self._w_c32_bwd = o.zeros(F_ * 9 * self.np_p) if self.cv_c32_bwd is not None else None
         self._dw_c32_tmp = None
         if self.cv_c32_bwd is not None:
@@ -707,6 +713,10 @@ class NativeGenerator:
                 for k in range(1, 6):
                     yield f"res_blocks.{i}.dense_blocks.{j}.b{k}.0", self.cv_b[k - 1]
         yield "conv2", self.cv_conv2
+        if self.f8_tail:
+            for u in range(self.nup):
+                yield f"upsampling.{3 * u}", self.cv_up[u]
+            yield "conv3.0", self.cv_c30
 
     def _requantise_weights(self):
         o, P = self.ops, self.P
@@ -838,13 +848,23 @@ class NativeGenerator:
             if wg8:      # the RRDB's three slabs are complete in the fp8 ring (four entries: the conv above wrote slice 0 of a fourth)
                 o.block_exp_max_batch([(self._qring[d % 4][1], self._ex_new[d]) for d in range(3 * i, 3 * i + 3)])
         kw = dict(xq=qs(self.ndrb, 0, F_), wq=self._wq["conv2"]) if f8 else {}
+        f8t = self.f8_tail
+        if f8t:
+            if self._tq is None:
+                qb = lambda t: (o.zeros(*t.shape, dtype=torch.uint8), o.zeros(*t.shape[:-1], F_ // 32, dtype=torch.uint8))
+                self._tq = [qb(self.trunk)] + [qb(t) for t in self.ups]
+            kw["out_q"] = self._tq[0]
         o.conv_fwd(self.cv_conv2, self._slab(self.ndrb, save)[..., :F_], W("conv2"), self.trunk, bias=Bz("conv2"),
                    r1=self.out1, s1=1.0, **kw)                                           # generator.py:86-87
         cur = self.trunk
         for u in range(self.nup):
-            o.conv_fwd(self.cv_up[u], cur, W(f"upsampling.{3 * u}"), self.ups[u], bias=Bz(f"upsampling.{3 * u}"), act=G_SLOPE)
+            name = f"upsampling.{3 * u}"
+            # (bf16 up-sampled tensor: read by the backward only -- masks, weight-gradient inputs)
+            kw = dict(xq=self._tq[u], wq=self._wq[name], out_q=self._tq[u + 1], skip_y=not save) if f8t else {}
+            o.conv_fwd(self.cv_up[u], cur, W(name), self.ups[u], bias=Bz(name), act=G_SLOPE, **kw)
             cur = self.ups[u]
-        o.conv_fwd(self.cv_c30, cur, W("conv3.0"), self.c30, bias=Bz("conv3.0"), act=G_SLOPE)
+        kw = dict(xq=self._tq[self.nup], wq=self._wq["conv3.0"]) if f8t else {}
+        o.conv_fwd(self.cv_c30, cur, W("conv3.0"), self.c30, bias=Bz("conv3.0"), act=G_SLOPE, **kw)
         o.conv_fwd(self.cv_c32, self.c30, W("conv3.2"), self.fake, bias=Bz("conv3.2"))
         return self.fake
 

@@ -118,6 +118,7 @@ class HipOps:
         self.f8_wgrad = os.environ.get("DG_NO_F8_WGRAD") is None     # fp8 weight gradients of the eligible critic layers (f8 mode only)
         self.f8_gbwd = os.environ.get("DG_NO_F8_GBWD") is None       # f8_generator: also the dense blocks' data gradients on the MXFP8 kernel
         self.f8_gwgrad = os.environ.get("DG_NO_F8_GWGRAD") is None   # ... and their weight gradients on the fp8 kernel (uniform-scale slab copies)
+        self.f8_gtail = os.environ.get("DG_NO_F8_GTAIL") is None     # f8_generator: also the forward of the up-sampling tail (upsampling.*, conv3.0)
         assert not self.f8 or dtype == "bf16", "the fp8 conv path quantises bf16 tensors"
         self._f8_scratch = {}
         if deterministic is None:
@@ -284,8 +285,11 @@ class HipOps:
             return (self.f8 and self.f8_wgrad and cv.net == "C" and not cv.pixel_shuffle and cv.Cin % 128 == 0
                     and cv.Cout % 128 == 0 and cv.Wo % 64 == 0)
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
-        # generator layers (net "G": the dense-block trunk): forward always in f8_generator mode, data gradients when f8_gbwd is on
+        # generator layers (net "G": the dense-block trunk): forward always in f8_generator mode, data gradients when f8_gbwd is on;
+        # net "T": the up-sampling tail's forward (pixel-shuffled outputs included) when f8_gtail is on
         nets = ("C", "G") if (self.f8_generator and (kind == "fwd" or self.f8_gbwd)) else ("C",)
+        if self.f8_generator and self.f8_gtail and kind == "fwd" and cv.net == "T":
+            return cred % 128 == 0 and nout > 64 and (not cv.pixel_shuffle or (cv.Cout // 4) % 32 == 0)
         return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
 
     def conv_fwd(self, cv: Conv, x, w_fwd, y, xq=None, wq=None, **ep):

@@ -229,6 +229,7 @@ class EmuOps:
     f8_wgrad = True
     f8_gbwd = True
     f8_gwgrad = True
+    f8_gtail = True
 
     def f8_eligible(self, cv, kind):
         if kind == "wgrad":
@@ -237,6 +238,9 @@ class EmuOps:
         cred, nout = (cv.Cin, cv.Cout) if kind == "fwd" else (cv.Cout, cv.Cin)
         # generator layers (net "G": the dense-block trunk): forward always in f8_generator mode, data gradients when f8_gbwd is on
         nets = ("C", "G") if (self.f8_generator and (kind == "fwd" or self.f8_gbwd)) else ("C",)
+        # net "T": the forward of the generator's up-sampling tail (pixel-shuffled outputs included) when f8_gtail is on
+        if self.f8_generator and self.f8_gtail and kind == "fwd" and cv.net == "T":
+            return cred % 128 == 0 and nout > 64 and (not cv.pixel_shuffle or (cv.Cout // 4) % 32 == 0)
         return self.f8 and cv.net in nets and cred % 128 == 0 and nout > 64 and not cv.pixel_shuffle
 
     @staticmethod

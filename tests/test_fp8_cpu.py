@@ -88,6 +88,45 @@ def test_generator_fp8_trunk_on_emulated_ops():
     assert float((outs[True][0] - outs[False][0]).norm() / outs[False][0].norm()) < 0.1
 
 
+def test_generator_fp8_tail_forward_on_emulated_ops():
+    """f8_gtail: the up-sampling convs and conv3.0 (generator.py:69-81,88-89) read MXFP8 forms written by their producers -- conv2's
+    epilogue and the up-sampling convs' own epilogues, in shuffled pixel order -- ; a forward that is not saved leaves the bf16
+    up-sampled tensors unwritten; the result stays close to the bf16 tail's."""
+    from downgan_amd import synthetic
+    from downgan_amd.engine import NativeGenerator
+    from downgan_amd.layout import nchw_to_nhwc_padded
+    torch.set_num_threads(4)
+    B, S, F_, cin, nrb, nup = 1, 8, 128, 2, 1, 2
+    coarse, _ = synthetic.tiles(B, cin, S)
+    xc = nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.float32)
+    outs = {}
+    for tail in (False, True):
+        ops = EmuOps("f32", f8_generator=True)
+        ops.f8_gtail = tail
+        seen = []
+        real = ops.conv_fwd
+        ops.conv_fwd = lambda cv, x, w, y, _r=real, _s=seen, **kw: (_s.append((cv.net, cv.pixel_shuffle, kw.get("xq") is not None, kw.get("out_q") is not None,
+                                                                               bool(kw.get("skip_y")))), _r(cv, x, w, y, **kw))[1]
+        G = NativeGenerator(ops, F_, cin, B, S, num_res_blocks=nrb, num_upsample=nup)
+        assert G.f8 and G.f8_tail == tail
+        G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb, num_upsample=nup))
+        fake = G.forward(xc, save=False).clone()
+        tcalls = [c for c in seen if c[0] == "T"]
+        assert tcalls == ([("T", True, True, True, True)] * nup + [("T", False, True, False, False)] if tail else [("T", True, False, False, False)] * nup + [("T", False, False, False, False)])
+        ups_unsaved = [float(t.abs().max()) for t in G.ups]
+        fake_saved = G.forward(xc, save=True).clone()
+        assert torch.equal(fake, fake_saved)                                       # the bf16 tensors are by-products only
+        assert all(float(t.abs().max()) > 0 for t in G.ups)
+        assert all(v == 0.0 for v in ups_unsaved) == tail                          # not stored by the unsaved forward in this mode
+        if tail:                                                                   # the shuffled copy is the quantised stored tensor
+            for u in range(nup):
+                q, sc, _ = EmuOps.mx_quant(G.ups[u])
+                assert torch.equal(G._tq[u + 1][0], q) and torch.equal(G._tq[u + 1][1], sc)
+        outs[tail] = fake
+    d = float((outs[True] - outs[False])[..., :2].norm() / outs[False][..., :2].norm())
+    assert 0 < d < 0.08, d
+
+
 def test_generator_fp8_data_gradients_on_emulated_ops():
     """f8_generator with f8_gbwd: the dense blocks' data gradients (autograd of generator.py:24-41) read the adjoint slab's MXFP8
     form -- slices written by the producing epilogues (activation mask + copy, residual + copy) and one quantiser call per RRDB

@@ -158,6 +158,45 @@ def test_fp8_engine_iteration_matches_emulated_engine():
         assert abs(a - b) <= 2e-2 * max(abs(b), 0.05), (k, a, b)
 
 
+@pytest.mark.parametrize("f8", [False, True])
+def test_pixel_shuffled_output_with_mxfp8_copy(f8):
+    """An up-sampling conv (generator.py:69-81: conv 128 -> 512, LeakyReLU, PixelShuffle(2)) whose epilogue also writes the MXFP8
+    form of the SHUFFLED tensor [N, 2H, 2W, 128] (scale bytes per destination pixel): bf16 kernel and fp8 kernel (net "T"), against
+    the emulation and bit for bit against dg_quant_mxfp8 of the stored tensor; skip_y leaves the bf16 tensor alone and writes the
+    same copy.  Ragged tile edges included."""
+    g = torch.Generator().manual_seed(41)
+    hip, emu = HipOps("bf16", f8_generator=True), EmuOps("bf16", f8_generator=True)
+    cv = Conv(2, 24, 40, 128, 512, 1, True, net="T" if f8 else "")
+    assert bool(hip.f8_eligible(cv, "fwd")) == f8
+    x = torch.randn(cv.N, cv.H, cv.W, cv.Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(cv.Cout * 9 * cv.Cin, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(cv.Cout, generator=g)
+    osh = hip.out_shape(cv)
+    assert osh == (2, 48, 80, 128)
+    qpair = lambda dev: (torch.zeros(osh, dtype=torch.uint8, device=dev), torch.zeros(osh[:-1] + (4,), dtype=torch.uint8, device=dev))
+    y_ref, oq_ref = torch.zeros(osh, dtype=torch.bfloat16), qpair("cpu")
+    emu.conv_fwd(cv, x, w, y_ref, bias=b, act=0.2, out_q=oq_ref)
+    y, oq = torch.zeros(osh, dtype=torch.bfloat16).cuda(), qpair("cuda")
+    hip.conv_fwd(cv, x.cuda(), w.cuda(), y, bias=b.cuda(), act=0.2, out_q=oq)
+    assert hip.lib.dg_last_conv_kernels() == (32 if f8 else 8)
+    close(y, y_ref, f"pixel-shuffled forward f8={f8}")
+    q_ref, s_ref = hip.quant_mxfp8(y)
+    assert torch.equal(oq[1], s_ref), int((oq[1] != s_ref).sum())
+    assert torch.equal(oq[0], q_ref), int((oq[0] != q_ref).sum())
+    y2 = torch.full(osh, 7.0, dtype=torch.bfloat16).cuda()
+    oq2 = qpair("cuda")
+    hip.conv_fwd(cv, x.cuda(), w.cuda(), y2, bias=b.cuda(), act=0.2, out_q=oq2, skip_y=True)
+    assert bool((y2 == 7.0).all()) and torch.equal(oq2[0], oq[0]) and torch.equal(oq2[1], oq[1])
+    # the consumer: a conv that reads the shuffled form (conv3.0 / the next up-sampling conv)
+    if f8:
+        cn = Conv(2, 48, 80, 128, 128, 1, False, net="T")
+        wn = (torch.randn(128 * 9 * 128, generator=g) * 0.05).to(torch.bfloat16)
+        z_ref, z = torch.zeros(2, 48, 80, 128, dtype=torch.bfloat16), torch.zeros(2, 48, 80, 128, dtype=torch.bfloat16).cuda()
+        emu.conv_fwd(cn, y.cpu(), wn, z_ref, act=0.2, xq=tuple(t.cpu() for t in oq))
+        hip.conv_fwd(cn, y2, wn.cuda(), z, act=0.2, xq=oq)            # y2 holds garbage: only the fp8 form is read
+        close(z, z_ref, "consumer of the shuffled fp8 form")
+
+
 @pytest.mark.parametrize("case", ["halo_bf16", "im2col_first_layer", "fp8_producer", "s2_dgrad_classes", "general_epilogue"])
 def test_fused_mxfp8_output_equals_quantised_store(case):
     """dg_epilogue.out_q / out_qs: the MXFP8 copy a conv epilogue writes beside its bf16 output is bit-identical to
@@ -220,11 +259,27 @@ def test_fp8_generator_trunk_matches_emulation():
     assert G.f8
     G.load_state_dict(pg)
     xc = ops.zeros(B, S, S, 16); ops.nchw_to_nhwc(torch.from_numpy(coarse).cuda(), xc)
+    # The trunk (residual paths) agrees to accumulation order; behind it every further MXFP8 stage turns the 0.4 % the two engines
+    # differ by into E4M3 code flips (~1.6 % of noise per stage): with the four tail layers in fp8 too (f8_gtail) the outputs differ
+    # by 0.06 of the largest value where the trunk-only mode differs by 0.007, and by 0.09 from the bf16 generator
+    # (tools/f8_tail_check.py).  Tight bound with the bf16 tail, loose with the fp8 tail -- whose layers are checked one by one,
+    # bit for bit, in test_pixel_shuffled_output_with_mxfp8_copy.
+    outs = []
     for save in (False, True):
         got = G.forward(xc, save=save).float().cpu()
         err = float((got - ref)[..., :2].abs().max()) / max(1e-6, float(ref[..., :2].abs().max()))
-        assert err < 3e-2, (save, err)
+        assert G.f8_tail and err < 0.12, (save, err)
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1])              # the unsaved forward skips the bf16 up-sampled tensors, nothing else
     close(G.trunk, emu.trunk, "fp8 trunk", tol=3e-2)
+    o2, e2 = HipOps("bf16", f8_generator=True), EmuOps("bf16", f8_generator=True)
+    o2.f8_gtail = e2.f8_gtail = False
+    G2, emu2 = NativeGenerator(o2, F_, cin, B, S, num_res_blocks=nrb), NativeGenerator(e2, F_, cin, B, S, num_res_blocks=nrb)
+    G2.load_state_dict(pg); emu2.load_state_dict(pg)
+    ref2 = emu2.forward(nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.bfloat16), save=False).float()
+    got2 = G2.forward(xc, save=False).float().cpu()
+    assert not G2.f8_tail and float((got2 - ref2)[..., :2].abs().max()) < 3e-2 * float(ref2[..., :2].abs().max())
+    del G2, emu2
     # backward: the dense blocks' data gradients on the MXFP8 kernel too (f8_gbwd: adjoint-slab forms written by the epilogues
     # with the activation mask / the residual, quantised virtual packs), weight gradients bf16 from the saved slabs
     assert G.f8_bwd and emu.f8_bwd
