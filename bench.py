@@ -288,8 +288,9 @@ def summarise_kernels(prof, elapsed, steps, peak, args, per_layer, with_traffic=
             return {"achieved": round(fl_ / sec_ / 1e12, 2) if sec_ > 0 else None, "frac": round(fl_ / sec_ / 1e12 / MFMA_PEAK_TFLOPS["fp8"], 4) if sec_ > 0 else None,
                     "launches": n_, "share_of_step": round(sec_ / elapsed, 3)}
         roofline["fp8_kernel"] = dict({"kernel": "every fp8 MFMA launch of the step: gg_halo4w_f8_kernel (MXFP8 conv forward / data gradient of the critic's wide "
-                                                 "layers, operand quantisation included; with --dtype fp8 also the generator trunk's forward) and wg3w_f8_kernel "
-                                                 "(uniform-scale E4M3 weight gradients of the critic's layers 1-7)", "bound": "mfma",
+                                                 "layers, operand quantisation included; with --dtype fp8 also the generator's dense-block trunk forward + data gradients and "
+                                                 "its up-sampling tail's forward) and wg3w_f8_kernel (uniform-scale E4M3 weight gradients of the critic's layers 1-7 "
+                                                 "and, from the second generator iteration on, of the generator's dense blocks)", "bound": "mfma",
                                        "peak": MFMA_PEAK_TFLOPS["fp8"], "unit": "TFLOP/s"}, **rate(f8c + f8w),
                                       conv=rate(f8c), weight_gradient=rate(f8w) if f8w else None)
     return roofline, critic_stack, kernels
@@ -302,8 +303,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "fp8", "fp8c"],
-                    help="default: the workload's own (bf16; fp8 for cfg5).  fp8 = BASELINE configs[4]: forward / data-gradient convs of the critic's 128..1024-channel layers AND the forward "
-                         "of the generator's dense-block trunk on the MXFP8 MFMA (fp32 accumulate), everything else as in bf16; "
+                    help="default: the workload's own (bf16; fp8 for cfg5).  fp8 = BASELINE configs[4]: forward / data-gradient convs of the critic's 128..1024-channel layers, of the generator's "
+                         "dense-block trunk and the forward of its up-sampling tail on the MXFP8 MFMA (fp32 accumulate), their weight gradients on the fp8 MFMA "
+                         "with uniform-scale operands, everything else as in bf16; "
                          "fp8c = the critic's layers only")
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -400,8 +402,9 @@ def main():
             e8, prof8 = timed_steps(eng8, ops8, xc8, xf8, al8, 1, 5, None, False, True, False)
             sc8 = eng8.read_scalars(True)
             r8, cs8, _ = summarise_kernels(prof8, e8, 5, MFMA_PEAK_TFLOPS["bf16"], args, False, with_traffic=False)
-            fp8 = {"what": "--dtype fp8 (BASELINE configs[4]: MXFP8 MFMA for the critic's wide convs forward + data gradient and the generator trunk's "
-                           "forward; weight gradients / tail / Linear / Adam as in bf16), same workload, 1 warm-up + 5 timed steps",
+            fp8 = {"what": "--dtype fp8 (BASELINE configs[4]: MXFP8 MFMA for the forward + data gradients of the critic's wide convs and of the generator's "
+                           "dense-block trunk and for the forward of its up-sampling tail, fp8 MFMA with uniform-scale operands for their weight gradients; "
+                           "first layers / conv3.2 / tail backward / Linear / Adam as in bf16), same workload, 1 warm-up + 5 timed steps",
                    "value": round(5 * B / e8, 4), "unit": "samples/s", "steps": 5, "ms_per_step": round(e8 / 5 * 1e3, 2),
                    "vs_bf16": round((5 * B / e8) / (args.steps * B / elapsed), 4),
                    "roofline": (r8 or {}).get("fp8_kernel"), "critic_stack_frac_of_bf16_peak": (cs8 or {}).get("mfma_frac"),
