@@ -22,7 +22,7 @@ class Epilogue(C.Structure):
                 ("mask", C.c_void_p), ("ldmask", C.c_int64), ("mask_slope", C.c_float),
                 ("accumulate", C.c_int), ("mask_bits", C.c_void_p), ("out_bits", C.c_void_p),
                 ("mask_c0", C.c_int), ("mask_last", C.c_int), ("out_q", C.c_void_p), ("out_qs", C.c_void_p), ("ldqs", C.c_int64),
-                ("out_u", C.c_void_p), ("out_ue", C.c_void_p), ("skip_y", C.c_int)]
+                ("out_u", C.c_void_p), ("out_ue", C.c_void_p), ("skip_y", C.c_int), ("out_amax", C.c_void_p)]
 
 
 class ConvGeom(C.Structure):
@@ -84,6 +84,7 @@ _PROTOS = {
     "dg_conv3x3_wgrad": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp],
     "dg_conv3x3_wgrad_dense": [_vp, _i, _vp, _vp, _vp, _vp, _vp],
     "dg_conv3x3_wgrad_f8": [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp, _vp],
+    "dg_exp_from_amax": [_vp, _i, _i, _vp, _vp],
     "dg_conv3x3_wgrad_dense_f8": [C.POINTER(ConvGeom), _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "dg_gather_gemm": [C.POINTER(GGDesc), C.POINTER(Epilogue), _vp, _vp, _vp, _vp],
     "dg_conv3x3_plan": [C.POINTER(ConvGeom), _i, C.POINTER(GGDesc)],

@@ -116,9 +116,13 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     a.mask_bits = ep->mask_bits; a.out_bits = ep->out_bits;
     a.out_q = ep->out_q; a.out_qs = ep->out_qs;
     a.out_u = ep->out_u; a.out_ue = (const unsigned char*)ep->out_ue;
-    if ((a.out_u != nullptr) != (a.out_ue != nullptr) || (a.out_u && !a.out_q)) return DG_ERR_BAD_ARG;
+    if ((a.out_u != nullptr) != (a.out_ue != nullptr)) return DG_ERR_BAD_ARG;
     a.no_y = ep->skip_y ? 1 : 0;
-    if (a.no_y && (!a.out_q || a.accumulate)) return DG_ERR_BAD_ARG;          // (the first-layer launcher checks its own shapes)
+    if (a.no_y && ((!a.out_q && !a.out_u) || a.accumulate)) return DG_ERR_BAD_ARG;          // (the first-layer launcher checks its own shapes)
+    // the uniform-scale copy WITHOUT the MXFP8 one and the magnitude census: the first-layer kernel's (gg_launch_im2col_t refuses other shapes)
+    a.out_amax = (unsigned*)ep->out_amax;
+    if (((a.out_u && !a.out_q) || a.out_amax) && !im2col_small) return DG_ERR_BAD_SHAPE;
+    if (a.out_u && (d->dtype != DG_BF16 || d->Nout < 128 || d->Nout % 64 || d->dst_ps)) return DG_ERR_BAD_SHAPE;
     // the MXFP8 copy is written by the 64-channel wave-tile epilogues of bf16 launches: same shape rules as the bit masks
     if ((a.out_q != nullptr) != (a.out_qs != nullptr)) return DG_ERR_BAD_ARG;
     if (a.out_q && (d->dtype != DG_BF16 || d->Nout < 128 || d->Nout % 64)) return DG_ERR_BAD_SHAPE;
@@ -146,8 +150,9 @@ static int gather_gemm_impl(const dg_gg_desc* d, const dg_epilogue* ep, const vo
     if ((long long)d->Cred * d->Nout * 18 <= (2ll << 20)) a.seg = 2;
   }
   if (f8) {
-    F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws, f8->ldxs > 0 ? (int)f8->ldxs : d->Cred / 32};
-    if (f.ldxs < d->Cred / 32 || f.ldxs % 4) return DG_ERR_BAD_SHAPE;          // the kernel fetches 4 scale bytes per pixel and K-step as one dword
+    // ldxs < 0: ONE scale row for every pixel (a uniform-scale source, dg_epilogue.out_u / out_ue: the kernel's scale fetches all hit row 0)
+    F8Args f{(const unsigned char*)f8->xs, (const unsigned char*)f8->ws, f8->ldxs > 0 ? (int)f8->ldxs : f8->ldxs < 0 ? 0 : d->Cred / 32};
+    if (f8->ldxs >= 0 && (f.ldxs < d->Cred / 32 || f.ldxs % 4)) return DG_ERR_BAD_SHAPE;          // the kernel fetches 4 scale bytes per pixel and K-step as one dword
     return gg_launch_f8(a, f, d->N, st);
   }
   static const bool no_im2col = getenv("DG_GG_NOIM2COL") != nullptr;

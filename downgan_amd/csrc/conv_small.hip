@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
   };
   // a group's pixels are fetched two groups ahead (memory operations retire in order: a load comes back only after the stores
   // issued before it have been acknowledged)
+  unsigned ab_run[2] = {0u, 0u};         // dg_epilogue.out_amax: largest block magnitude (bit pattern) this lane stored, per 64-channel half
   unsigned x0 = gather(grp_of(0)), x1 = gather(grp_of(1));
   for (int it = 0;; ++it) {
     const int grp = grp_of(it);
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
         Mma<T>::run(fa[4 * h + j], fb, acc[j]);
       }
       epi64_pixel<T, true, F | 512 | ((F & 4) ? 1024 : 0)>(a, R, acc[0], acc[1], acc[2], acc[3], zero16, offy[h], 0u, 0u, 0u, boff[h], mb[h],
-                                                            false, &ob[h], inv_u[h]);
+                                                            false, &ob[h], inv_u[h], (F & 2304) ? &ab_run[h] : nullptr);
     }
     if (F & 4) {
       const int both = (int)(ob[0] | (ob[1] << 16));
@@ -461,6 +462,17 @@ __global__ __launch_bounds__(256, 4) void gg_im2col_direct_kernel(const GGArgs a
       __builtin_amdgcn_raw_buffer_store_b32(lo | (hi << 16), R.rbo, ob_off, 0, 0);
     }
     x0 = x1; x1 = x2;
+  }
+  if constexpr ((F & 2304) != 0) {       // one atomic per (wave, 32-channel block): the lane pair (g, g ^ 1) already holds its block's maximum
+    if (a.out_amax) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned m = ab_run[h];
+#pragma unroll
+        for (int sft = 1; sft < 16; sft <<= 1) { const unsigned o2 = (unsigned)__shfl_xor((int)m, sft, 64); m = m > o2 ? m : o2; }
+        if (l15 == 0 && (g & 1) == 0) atomicMax(a.out_amax + ((c0 + 64 * h + 16 * g) >> 5), m);
+      }
+    }
   }
 }
 
@@ -476,8 +488,9 @@ static int gg_launch_im2col_t(GGArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     constexpr bool no_direct = false;
     const int F = (a.has_act ? 1 : 0) | (a.mask_bits ? 2 : 0) | (a.out_bits ? 4 : 0) | (a.out_q ? 256 : 0) | (a.out_u ? 2048 : 0) | (a.no_y ? 4096 : 0);
-    const bool f_ok = F == 0 || F == 1 || F == 2 || F == 5 || F == 258 || F == 261 || F == 2306 || F == 2309 || F == 4354 || F == 4357 || F == 6402 || F == 6405;
-    if ((a.out_u || a.no_y) && !(f_ok && !no_direct && lean && a.Wg % 16 == 0 && a.Nout % 128 == 0 && a.Hs == a.Hg && a.Ws == a.Wg)) return DG_ERR_BAD_SHAPE;
+    const bool f_ok = F == 0 || F == 1 || F == 2 || F == 5 || F == 258 || F == 261 || F == 2306 || F == 2309 || F == 4354 || F == 4357 || F == 6402 || F == 6405 ||
+                      F == 6146 || F == 6149;      // (the uniform-scale copy ALONE: mask bits / activation + bits, no bf16 store)
+    if ((a.out_u || a.no_y || a.out_amax) && !(f_ok && !no_direct && lean && a.Wg % 16 == 0 && a.Nout % 128 == 0 && a.Hs == a.Hg && a.Ws == a.Wg)) return DG_ERR_BAD_SHAPE;
     if (!no_direct && lean && a.Wg % 16 == 0 && a.Nout % 128 == 0 && a.Hs == a.Hg && a.Ws == a.Wg &&
         (long long)a.M * a.ldy * 2 < (1ll << 46) && f_ok) {
       const int ngroups = a.M / 16;
@@ -498,6 +511,8 @@ static int gg_launch_im2col_t(GGArgs& a, hipStream_t st) {
         case 4354: hipLaunchKernelGGL((gg_im2col_direct_kernel<4354>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
         case 4357: hipLaunchKernelGGL((gg_im2col_direct_kernel<4357>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
         case 6402: hipLaunchKernelGGL((gg_im2col_direct_kernel<6402>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 6146: hipLaunchKernelGGL((gg_im2col_direct_kernel<6146>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
+        case 6149: hipLaunchKernelGGL((gg_im2col_direct_kernel<6149>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
         default: hipLaunchKernelGGL((gg_im2col_direct_kernel<6405>), grid, dim3(256), 0, st, a, ngroups, tiled); break;
       }
       return dg_check_launch();

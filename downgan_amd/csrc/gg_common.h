@@ -44,6 +44,7 @@ struct GGArgs {
   void* out_q; void* out_qs;                 // MXFP8 copy of the stored output (dg_epilogue.out_q / out_qs)
   void* out_u; const unsigned char* out_ue;  // uniform-scale E4M3 copy for the fp8 weight gradient (dg_epilogue.out_u / out_ue)
   int no_y;                                  // dg_epilogue.skip_y: the bf16 output itself is not stored (only its fp8 copies / mask bits are read)
+  unsigned* out_amax;                        // dg_epilogue.out_amax: per 32-channel block, atomic max of the bit pattern of the largest |stored value| (first-layer kernel)
   int ldqs, qs_shift;                        // scale bytes per pixel of out_qs; log2(Nout / 16) when that stride is not Nout / 32
   long long ldx, ldw, ldy, ldr1, ldr2, ldmask;
   int M, Hg, Wg, Hs, Ws;
@@ -160,7 +161,7 @@ template <typename T, bool LEAN, int F = -1>
 __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, const f32x4_t& f0, const f32x4_t& f1, const f32x4_t& f2,
                                             const f32x4_t& f3, const float (&bias)[16], unsigned offy, unsigned off1, unsigned off2,
                                             unsigned offm, unsigned boff, unsigned mb, bool mask_on, unsigned* ob_ret = nullptr,
-                                            float inv_u = 0.f) {
+                                            float inv_u = 0.f, unsigned* ab_run = nullptr) {
   typedef EpiV<T> IO;
   constexpr int NU = IO::NU, CPU = IO::CPU;
   u32x4_t v1[NU], v2[NU], vm[NU], va[NU];
@@ -252,26 +253,30 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
     // holds 16 consecutive channels, lane ^ 16 the other half of the 32-channel block; one 16-byte store per lane, the scale byte
     // from the lane with the lower half.  q has y's pixel stride (in bytes = elements), scales [pixel][Nout / 32]:
     // byte offsets offy / 2 and boff / 4 ((rel * Nout + channel) / 32).
-    if (f_q) {
+    if (f_q || f_u) {
       float w[16];
       IO::unpack(pk[0], w); IO::unpack(pk[1], w + 8);
       unsigned ab = mx_amax_bits16(w);                                // (a NaN / Inf in the block dominates: mx_poison)
       const unsigned ab2 = (unsigned)__shfl_xor((int)ab, 16, 64);
       ab = ab > ab2 ? ab : ab2;
-      const int e = mx_scale_byte(__uint_as_float(ab));
-      const u32x4_t qv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, mx_inv_scale(e)), ab));
-      __builtin_amdgcn_raw_buffer_store_b128(qv, R.rq, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
-      const bool low_half = ((threadIdx.x >> 4) & 1) == 0;
-      unsigned offqs = boff >> 2;                                   // dense scale rows: (rel * Nout + channel) / 32
-      if (a.qs_shift) {                                             // a channel slice of a wider tensor (dense-block slab) / a pixel-shuffled output
-        const unsigned w16 = boff >> 1;                             // pixel * (C / 16) + channel / 16, C / 16 a power of two (C = channels per destination pixel)
-        offqs = (w16 >> a.qs_shift) * (unsigned)a.ldqs + ((w16 & ((1u << a.qs_shift) - 1u)) >> 1);
+      if (f_q) {
+        const int e = mx_scale_byte(__uint_as_float(ab));
+        const u32x4_t qv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, mx_inv_scale(e)), ab));
+        __builtin_amdgcn_raw_buffer_store_b128(qv, R.rq, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
+        const bool low_half = ((threadIdx.x >> 4) & 1) == 0;
+        unsigned offqs = boff >> 2;                                   // dense scale rows: (rel * Nout + channel) / 32
+        if (a.qs_shift) {                                             // a channel slice of a wider tensor (dense-block slab) / a pixel-shuffled output
+          const unsigned w16 = boff >> 1;                             // pixel * (C / 16) + channel / 16, C / 16 a power of two (C = channels per destination pixel)
+          offqs = (w16 >> a.qs_shift) * (unsigned)a.ldqs + ((w16 & ((1u << a.qs_shift) - 1u)) >> 1);
+        }
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, R.rqs, (low_half && boff != DG_OOB_OFF) ? offqs : DG_OOB_OFF, 0, 0);
       }
-      __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, R.rqs, (low_half && boff != DG_OOB_OFF) ? offqs : DG_OOB_OFF, 0, 0);
       if (f_u) {     // the same rounded values on the tensor-wide exponent of their 32-channel block (a non-finite block is poisoned too)
         const u32x4_t uv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, inv_u), ab));
         __builtin_amdgcn_raw_buffer_store_b128(uv, R.ru, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
       }
+      // running maximum of the block magnitudes this lane has stored (dg_epilogue.out_amax; a dropped pixel's values are not stored)
+      if (ab_run && offy != DG_OOB_OFF) *ab_run = *ab_run > ab ? *ab_run : ab;
     }
   }
 }

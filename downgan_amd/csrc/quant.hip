@@ -119,7 +119,11 @@ __global__ void block_exp_finish_kernel(const dg_exp_batch b, unsigned* __restri
   const int ti = blockIdx.x, k = threadIdx.x;
   unsigned* tmp = tmp_all + ti * 64;
   if (k < b.nblocks[ti]) {
-    const unsigned v = tmp[k] + (unsigned)margin;
+    unsigned v = tmp[k] + (unsigned)margin;
+    // passes over one buffer alternate between inputs of different size (real / generated samples: 20x apart at initialisation), and
+    // exponents taken from the smaller one saturate the larger one's copy at 448 * 2^e: an exponent falls by at most ONE per update
+    const unsigned old = reinterpret_cast<unsigned char*>(b.out[ti])[k];
+    if (old > 0u && v + 1u < old) v = old - 1u;
     reinterpret_cast<unsigned char*>(b.out[ti])[k] = (unsigned char)(v > 254u ? 254u : v);
     tmp[k] = 0u;
   }
@@ -148,6 +152,26 @@ extern "C" int dg_block_exp_max(const void* scales, int64_t rows, int64_t ld, in
   dg_exp_batch b{};
   b.n = 1; b.scales[0] = scales; b.rows[0] = rows; b.ld[0] = ld; b.nblocks[0] = nblocks; b.out[0] = out;
   return dg_block_exp_max_batch(&b, margin, scratch, stream);
+}
+
+// dg_epilogue.out_amax -> exponents: out[b] = min(254, mx_scale_byte(largest magnitude of block b) + margin) -- what dg_block_exp_max gives
+// for the MXFP8 scale bytes of the same tensor (the largest per-pixel block exponent IS the exponent of the largest value) -- and the
+// census is cleared for the next pass.
+__global__ void exp_from_amax_kernel(unsigned* __restrict__ amax, int nblocks, int margin, unsigned char* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k < nblocks) {
+    unsigned v = (unsigned)mx_scale_byte(__uint_as_float(amax[k])) + (unsigned)margin;
+    const unsigned old = out[k];
+    if (old > 0u && v + 1u < old) v = old - 1u;       // (falls by at most one per update, as in block_exp_finish_kernel)
+    out[k] = (unsigned char)(v > 254u ? 254u : v);
+    amax[k] = 0u;
+  }
+}
+extern "C" int dg_exp_from_amax(void* amax, int nblocks, int margin, void* out, void* stream) {
+  if (!amax || !out) return DG_ERR_BAD_ARG;
+  if (nblocks <= 0 || nblocks > 64 || margin < 0 || margin > 8 || reinterpret_cast<uintptr_t>(amax) % 4) return DG_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(exp_from_amax_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), (unsigned*)amax, nblocks, margin, (unsigned char*)out);
+  return dg_check_launch();
 }
 
 // ---- stand-alone uniform-scale quantiser (the conv epilogues write this form themselves, dg_epilogue.out_u; this is for the one

@@ -295,6 +295,15 @@ class NativeCritic:
         self.tan_exp = [o.zeros(self.acts[l].shape[-1] // 32, dtype=torch.uint8) if l + 1 < 8 and self.wg8[l + 1] else None for l in range(8)]
         self._tanu = None
         self.skip_dead = os.environ.get("DG_F8_KEEP_BF16") is None      # do not store bf16 tensors that only fp8 readers follow (dg_epilogue.skip_y)
+        # The first layer's 8.6-GB output (store-bound launch) and its tangent: once exponents exist they are written as the
+        # uniform-scale copy ALONE -- layer 1's MXFP8 conv reads that copy with the exponents as one scale row for every pixel, its
+        # fp8 weight gradient reads it anyway -- and the launch keeps the census of magnitudes the next exponents come from itself
+        # (dg_epilogue.out_amax, ops.exp_from_amax): half the bytes of those launches.
+        self.l0u = (self.f8 and bool(getattr(o, "f8_l0u", False)) and self._l0_f8_out and self.wg8[1] and self.skip_dead and self.act_bits is not None
+                    and self.actu[0] is not None and self.tan_exp[0] is not None)
+        nb0 = self.acts[0].shape[-1] // 32
+        self._a0_amax = o.zeros(nb0, dtype=torch.int32) if self.l0u else None
+        self._t0_amax = o.zeros(nb0, dtype=torch.int32) if self.l0u else None
         self._act_exp_ok = self._us_exp_ok = self._tan_exp_ok = False     # exponents of the role initialised by an earlier pass
         self._u_act_live = False                                          # this pass's forward wrote valid uniform-scale activations
 
@@ -355,15 +364,22 @@ class NativeCritic:
         cur = x
         want_u = self.f8 and for_wgrad and self._act_exp_ok
         self._u_act_live = want_u
+        l0u = self.l0u and self._act_exp_ok           # the first layer's output: uniform-scale copy alone (every pass, once exponents exist)
         for l, cv in enumerate(self.convs):
             f8kw = dict(xq=self.actq[l - 1] if l else None, wq=self.wq_f[l], out_q=self.actq[l]) if self.f8 else {}
             if want_u and self.actu[l] is not None:
                 f8kw["out_u"] = self.actu[l]
+            if l0u and l == 0:
+                f8kw = dict(out_u=self.actu[0], out_amax=self._a0_amax, skip_y=True)
+            elif l0u and l == 1:
+                f8kw["xq"] = self.actu[0]             # (bytes, block exponents): the exponents are the scale row of every pixel
+            elif self.l0u and l == 0:                 # bootstrap pass: MXFP8 copy as before, and the census starts
+                f8kw["out_amax"] = self._a0_amax
             # the bf16 activation itself is dead when the next conv reads the MXFP8 copy, the masks are bits and the only other
             # reader -- layer l + 1's weight gradient -- is the fp8 kernel (or does not run in this pass): not stored then
             if self.f8 and self.skip_dead and l <= 6 and self.actq[l] is not None and self.act_bits is not None \
                     and (o.f8_eligible(cv, "fwd") or (l == 0 and self._l0_f8_out)) \
-                    and (not for_wgrad or (want_u and self.wg8[l + 1] and self._us_exp_ok)):
+                    and (not for_wgrad or (want_u and self.wg8[l + 1] and self._us_exp_ok)) and not (l0u and l == 0):
                 f8kw["skip_y"] = True
             o.conv_fwd(cv, cur, P.w(f"features.{2 * l}.weight"), self.acts[l],
                        bias=P.master("features.0.bias") if l == 0 else None, act=C_SLOPE,
@@ -445,6 +461,9 @@ class NativeCritic:
         pairs = []
         for l in range(8):
             if role == "loss" and self.actu[l] is not None:
+                if l == 0 and self.l0u:       # the first layer's launches kept the census themselves (no MXFP8 scale bytes in that mode)
+                    self.ops.exp_from_amax(self._a0_amax, self.actu[0][1])
+                    continue
                 pairs.append((self.actq[l][1], self.actu[l][1]))
             if self.usu[l] is not None:
                 pairs.append((self.usq[l][1], self.usu[l][1] if role == "loss" else self.us_exp_gp[l]))
@@ -501,13 +520,14 @@ class NativeCritic:
                 if any(e is not None for e in self.tan_exp):
                     self._tanu = [o.zeros(big, dtype=torch.uint8) for _ in range(2)]
         t, tq, tu = v_buf, None, None          # the tangent t_{l-1}, its MXFP8 form, its uniform-scale form (bytes, exponents)
+        t0_census = False                      # l0u: t_0 exists as its uniform-scale copy alone (tq = that copy, the exponents its scale row)
         for l, cv in enumerate(self.convs):
             name = f"features.{2 * l}.weight"
             if self.f8 and self.wg8[l] and tu is not None and getattr(self, "_us_live", False) and r0 == 0:
                 o.conv_wgrad_f8(cv, tu[0], tu[1], self.usu[l][0], self.us_exp_gp[l], P.grad(name).reshape(-1))
             else:
                 o.conv_wgrad(cv, t, us[l], P.grad(name).reshape(-1))
-            if self.f8 and l > 0 and self.tan_exp[l - 1] is not None and tq is not None:
+            if self.f8 and l > 0 and self.tan_exp[l - 1] is not None and tq is not None and not (l == 1 and t0_census):
                 o.block_exp_max(tq[1], self.tan_exp[l - 1])     # t_{l-1}'s copy has been consumed: exponents for the next tangent pass
             tn = self._tan[l & 1][:self.acts[l].numel()].view(self.acts[l].shape)
             if l == 7 and fc1_slot is not None:           # FC1's tangent input rows stay for fc1_flush
@@ -525,10 +545,15 @@ class NativeCritic:
                 if self.skip_dead and bits and l < 7 and self.wg8[l + 1] and getattr(self, "_us_live", False) \
                         and (o.f8_eligible(cv, "fwd") or (l == 0 and self._l0_f8_out)):
                     f8kw["skip_y"] = True        # the bf16 tangent: read by the next conv (MXFP8 copy) and layer l + 1's fp8 weight gradient only
+            if self.l0u and l == 0 and tun is not None and f8kw.get("skip_y") and r0 == 0:
+                f8kw = dict(out_u=tun, out_amax=self._t0_amax, skip_y=True)
+                tqn, t0_census = tun, True
             if bits:
                 o.conv_fwd(cv, t, P.w(name), tn, mask_bits=bits[l], mask_slope=C_SLOPE, **f8kw)
             else:
                 o.conv_fwd(cv, t, P.w(name), tn, mask=acts[l], mask_slope=C_SLOPE, **f8kw)
+            if l == 1 and t0_census:          # layer 1's launches have read t_0's copy with the old exponents: the next pass's from the census
+                o.exp_from_amax(self._t0_amax, self.tan_exp[0])
             t, tq, tu = tn, tqn, tun
         if self.f8 and any(e is not None for e in self.tan_exp):
             self._tan_exp_ok = True

@@ -119,6 +119,7 @@ class HipOps:
         self.f8_gbwd = os.environ.get("DG_NO_F8_GBWD") is None       # f8_generator: also the dense blocks' data gradients on the MXFP8 kernel
         self.f8_gwgrad = os.environ.get("DG_NO_F8_GWGRAD") is None   # ... and their weight gradients on the fp8 kernel (uniform-scale slab copies)
         self.f8_gtail = os.environ.get("DG_NO_F8_GTAIL") is None     # f8_generator: also the forward of the up-sampling tail (upsampling.*, conv3.0)
+        self.f8_l0u = os.environ.get("DG_NO_F8_L0U") is None         # fp8 mode: the critic's first layer writes the uniform-scale copy of its output alone
         assert not self.f8 or dtype == "bf16", "the fp8 conv path quantises bf16 tensors"
         self._f8_scratch = {}
         if deterministic is None:
@@ -224,7 +225,8 @@ class HipOps:
         return (N, H, W, Cc // 64, 4)
 
     def _epilogue(self, out, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None, mask_slope=1.0,
-                  accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None, skip_y=False):
+                  accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None, skip_y=False,
+                  out_amax=None):
         ep = Epilogue()
         ep.bias = bias.data_ptr() if bias is not None else None
         if bias is not None:
@@ -262,13 +264,16 @@ class HipOps:
             assert all(qs.stride(i) * out.stride(2) == out.stride(i) * qs.stride(2) for i in range(3)), (qs.stride(), out.stride())
             ep.out_q, ep.out_qs, ep.ldqs = q.data_ptr(), qs.data_ptr(), qs.stride(2)
         if out_u is not None:       # (u8, exps): the uniform-scale E4M3 copy for the fp8 weight gradient (one exponent per 32-channel block)
-            u, ue = out_u
-            assert out_q is not None and u.dtype == torch.uint8 and u.shape == out.shape and u.stride() == out.stride()
+            u, ue = out_u           # (without out_q: first-layer launches only -- the library refuses the others)
+            assert u.dtype == torch.uint8 and u.shape == out.shape and u.stride() == out.stride()
             assert ue.dtype == torch.uint8 and ue.is_contiguous() and ue.numel() == out.shape[-1] // 32
             ep.out_u, ep.out_ue = u.data_ptr(), ue.data_ptr()
         if skip_y:                  # the bf16 output is not stored: only its fp8 copies / mask bits (nobody reads the tensor itself)
-            assert out_q is not None and not accumulate
+            assert (out_q is not None or out_u is not None) and not accumulate
             ep.skip_y = 1
+        if out_amax is not None:    # census of the largest stored magnitude per 32-channel block (uint32 bit patterns; first-layer launches)
+            assert out_amax.dtype == torch.int32 and out_amax.is_cuda and out_amax.is_contiguous() and out_amax.numel() == out.shape[-1] // 32
+            ep.out_amax = out_amax.data_ptr()
         return ep
 
     # ------------------------------------------------------------------ conv family
@@ -373,6 +378,12 @@ class HipOps:
 
     _exp_scratch = None
 
+    def exp_from_amax(self, amax, out, margin=1):
+        """out[b] (uint8) = the exponent of the uniform-scale copy of the NEXT pass from the census ``amax`` (int32 [C / 32]: bit patterns
+        of the largest stored magnitudes, dg_epilogue.out_amax) -- what block_exp_max derives from MXFP8 scale bytes; clears the census."""
+        assert amax.dtype == torch.int32 and out.dtype == torch.uint8 and amax.numel() == out.numel() and amax.is_contiguous() and out.is_contiguous()
+        check(self.lib.dg_exp_from_amax(_ptr(amax), amax.numel(), int(margin), _ptr(out), self._stream()), "dg_exp_from_amax")
+
     def quant_uniform(self, src, q, exps):
         """q = the uniform-scale E4M3 form of src [..., C] (one exponent per 32-channel block, ``exps`` uint8 [C / 32]): dg_quant_uniform."""
         Cc = src.shape[-1]
@@ -402,10 +413,17 @@ class HipOps:
         if wq is None:
             wq = self.quant_mxfp8(w.view(nout * 9, cred), self._f8_buf("wq", (nout * 9, cred)), self._f8_buf("ws", (nout * 9, cred // 32)))
         (xqq, xs), (wqq, ws) = xq, wq
-        assert xqq.shape == src.shape and xqq.stride(-1) == 1 and tuple(xs.shape) == tuple(src.shape[:-1]) + (cred // 32,), (xqq.shape, xs.shape, src.shape)
-        assert pix_layout(xqq)[1] == pix_layout(src)[1] and all(xs.stride(i) * xqq.stride(2) == xqq.stride(i) * xs.stride(2) for i in range(3))
+        assert xqq.shape == src.shape and xqq.stride(-1) == 1, (xqq.shape, src.shape)
+        if xs.dim() == 1:           # a UNIFORM-scale source (dg_epilogue.out_u): one row of block exponents for every pixel
+            assert xs.numel() == cred // 32 and xs.is_contiguous() and xs.dtype == torch.uint8
+            ldxs = -1
+        else:
+            assert tuple(xs.shape) == tuple(src.shape[:-1]) + (cred // 32,), (xs.shape, src.shape)
+            assert all(xs.stride(i) * xqq.stride(2) == xqq.stride(i) * xs.stride(2) for i in range(3))
+            ldxs = xs.stride(2)
+        assert pix_layout(xqq)[1] == pix_layout(src)[1]
         assert wqq.numel() == nout * 9 * cred and wqq.is_contiguous() and ws.numel() == nout * 9 * (cred // 32) and ws.is_contiguous()
-        q = _lib.F8Operands(xq=xqq.data_ptr(), xs=xs.data_ptr(), ldxq=xqq.stride(2), ldxs=xs.stride(2), wq=wqq.data_ptr(), ws=ws.data_ptr())
+        q = _lib.F8Operands(xq=xqq.data_ptr(), xs=xs.data_ptr(), ldxq=xqq.stride(2), ldxs=ldxs, wq=wqq.data_ptr(), ws=ws.data_ptr())
         return fn(C.byref(g), C.byref(e), C.byref(q), _ptr(dst), self._stream())
 
     def conv_wgrad(self, cv: Conv, x, dy, dw, db=None):

@@ -81,9 +81,15 @@ typedef struct dg_epilogue {
    * derives them from an earlier pass, dg_block_exp_max).  Needs out_q (the copy is formed from the same rounded values). */
   void* out_u;
   const void* out_ue;
-  /* != 0: the output tensor y itself is NOT stored -- only its fp8 copies (out_q required) / mask bits are, for launches whose bf16
-   * result nobody reads (fp8 mode: the next conv reads out_q, the weight gradient out_u, the masks out_bits).  Not with accumulate. */
+  /* != 0: the output tensor y itself is NOT stored -- only its fp8 copies (out_q or out_u required) / mask bits are, for launches whose
+   * bf16 result nobody reads (fp8 mode: the next conv reads out_q, the weight gradient out_u, the masks out_bits).  Not with accumulate. */
   int skip_y;
+  /* First-layer launches (<= 2 real input channels, critic.py:21-24: an 8.6-GB output at configs[1], store-bound) may write out_u
+   * WITHOUT out_q -- the next layer's MXFP8 conv then reads the uniform-scale copy with out_ue as ONE scale row for every pixel
+   * (dg_f8_operands.ldxs < 0): half the bytes -- and keep the census the exponents of the next pass come from themselves:
+   * out_amax [Cout / 32] uint32 (device, zeroed by the caller / by dg_exp_from_amax), atomically maxed with the bit pattern of the
+   * largest |stored value| of each 32-channel block.  Other launches return DG_ERR_BAD_SHAPE for either. */
+  void* out_amax;
 } dg_epilogue;
 
 /* Geometry of ONE reference nn.Conv2d(Cin, Cout, kernel_size=3, stride, padding=1) layer
@@ -357,10 +363,15 @@ typedef struct dg_f8_operands {
   const void* xq;   /* fp8 source, NHWC */
   const void* xs;   /* its scales [pixels][ldxs] (the first Cred/32 bytes of each row are used) */
   int64_t ldxq;     /* pixel stride of xq in bytes */
-  int64_t ldxs;     /* scale bytes per pixel of xs; 0 = Cred/32 (dense); a multiple of 4 */
+  int64_t ldxs;     /* scale bytes per pixel of xs; 0 = Cred/32 (dense); a multiple of 4; < 0 = xs is ONE row of Cred/32 exponents valid for every pixel (a uniform-scale source) */
   const void* wq;   /* fp8 weight pack [Nout][9][Cred] */
   const void* ws;   /* its scales [Nout][9][Cred/32] */
 } dg_f8_operands;
+/* out[b] = min(254, E8M0 exponent byte of the magnitude in amax[b] (floor(log2) - 8 + 127, >= 0) + margin), b < nblocks <= 64, and amax[b] = 0:
+ * turns the census a first-layer launch kept (dg_epilogue.out_amax) into the exponents of the next pass's uniform-scale copy -- the same
+ * values dg_block_exp_max derives from the MXFP8 scale bytes of that tensor. */
+int dg_exp_from_amax(void* amax, int nblocks, int margin, void* out, void* stream);
+
 /* out[b] = min(254, max over rows r of scales[r * ld + b] + margin), b < nblocks: the largest MXFP8 block exponent a tensor's
  * 32-channel block b reached anywhere (scales = the E8M0 bytes dg_quant_mxfp8 / dg_epilogue.out_qs wrote) -- the per-block exponent
  * of the uniform-scale copy (dg_epilogue.out_u) of the NEXT pass over the same tensor.  nblocks <= 64, a multiple of 4; `scratch`

@@ -85,9 +85,10 @@ class EmuOps:
         return torch.stack([(w[..., blk[c], g[c]] >> int(b[c])) & 1 for c in range(Cc)], dim=-1).bool()
 
     def _gather_gemm(self, d, x, w, y, bias=None, act=None, r1=None, s1=1.0, r2=None, s2=1.0, mask=None,
-                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None, skip_y=False):
+                     mask_slope=1.0, accumulate=False, mask_bits=None, out_bits=None, mask_c0=0, mask_last=False, out_q=None, out_u=None, skip_y=False,
+                     out_amax=None):
         if skip_y:      # dg_epilogue.skip_y: the fp8 copies / mask bits are formed from the values the launch WOULD store; y keeps its content
-            assert out_q is not None and not accumulate
+            assert (out_q is not None or out_u is not None) and not accumulate
             y = y.clone()
         N = d.N
         xs = x.float()
@@ -155,8 +156,12 @@ class EmuOps:
             out_q[0].copy_(q)
             out_q[1].copy_(s)
         if out_u is not None:      # uniform-scale E4M3 copy (one exponent per 32-channel block of the whole tensor): dg_epilogue.out_u
-            assert out_q is not None
+            assert out_q is not None or d.Cred <= 16      # (alone: first-layer launches)
             out_u[0].copy_(self.uq_quant(y, out_u[1])[0])
+        if out_amax is not None:   # dg_epilogue.out_amax: running maximum of the stored magnitudes' bit patterns per 32-channel block
+            Cc = y.shape[-1]
+            m = y.float().abs().reshape(-1, Cc // 32, 32).amax(dim=(0, 2)).contiguous().view(torch.int32)
+            out_amax.copy_(torch.maximum(out_amax, m))
 
     # ---- uniform-scale fp8 (csrc/gg_common.h epi64_pixel f_u; csrc/wgrad.hip wg3w_f8_kernel): E4M3 elements, ONE E8M0 exponent
     # per 32-channel block for the whole tensor -- the operand format of the fp8 weight gradient, whose contraction runs over pixels
@@ -187,7 +192,15 @@ class EmuOps:
 
     def block_exp_max(self, scales, out, margin=1):
         nb = scales.shape[-1]
-        out.copy_((scales.reshape(-1, nb).to(torch.int32).amax(0) + int(margin)).clamp(max=254).to(torch.uint8))
+        v = (scales.reshape(-1, nb).to(torch.int32).amax(0) + int(margin)).clamp(max=254)
+        out.copy_(self._exp_decay(v, out).to(torch.uint8))
+
+    @staticmethod
+    def _exp_decay(v, old):
+        """An exponent falls by at most ONE per update (csrc/quant.hip block_exp_finish_kernel): passes over one buffer alternate between
+        inputs of different size, and exponents taken from the smaller one would saturate the larger one's copy."""
+        o = old.reshape(-1).to(torch.int32)
+        return torch.where((o > 0) & (v + 1 < o), o - 1, v)
 
     def conv_wgrad_f8(self, cv, xq, ex, dyq, ey, dw):
         assert cv.Cin % 128 == 0 and cv.Cout % 128 == 0 and cv.Wo % 64 == 0 and not cv.pixel_shuffle
@@ -230,6 +243,7 @@ class EmuOps:
     f8_gbwd = True
     f8_gwgrad = True
     f8_gtail = True
+    f8_l0u = True
 
     def f8_eligible(self, cv, kind):
         if kind == "wgrad":
@@ -252,8 +266,16 @@ class EmuOps:
         return (v * sc).reshape(q.shape)
 
     def _f8_operand(self, t, pre):
-        """dequantised fp32 value of an operand: from its producer-written MXFP8 form if given, else quantised here."""
+        """dequantised fp32 value of an operand: from its producer-written MXFP8 form if given (a 1-D scale tensor = the block
+        exponents of a UNIFORM-scale form, valid for every pixel), else quantised here."""
+        if pre is not None and pre[1].dim() == 1:
+            return self.uq_dequant(pre[0], pre[1]).reshape(t.shape)
         return self.mx_dequant(*pre).reshape(t.shape) if pre is not None else self.mx_quant(t)[2]
+
+    def exp_from_amax(self, amax, out, margin=1):
+        e = ((((amax >> 23) & 0xff) - 8).clamp(min=0) + int(margin)).clamp(max=254)
+        out.copy_(self._exp_decay(e, out).to(torch.uint8))
+        amax.zero_()
 
     @staticmethod
     def _widen(cv, x):

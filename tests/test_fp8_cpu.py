@@ -252,6 +252,7 @@ def test_engine_fp8_weight_gradients_after_the_first_pass():
     for wg8 in (False, True):
         ops = EmuOps("f32", f8_critic=True)
         ops.f8_wgrad = wg8
+        ops.f8_l0u = False            # (the first layer's uniform-scale-only output changes the FORWARD: its own test below)
         calls = []
         real = ops.conv_wgrad_f8
         ops.conv_wgrad_f8 = lambda cv, *a, _r=real: (calls.append((cv.Cin, cv.Cout, cv.H)), _r(cv, *a))[1]
@@ -275,3 +276,53 @@ def test_engine_fp8_weight_gradients_after_the_first_pass():
     assert 0 < float((ga - gb).norm()) < 0.05 * float(ga.norm())
     for k in ("c_real_mean", "c_fake_mean", "gp_ret"):
         assert res[False][2][k] == res[True][2][k], k                       # the forward and the penalty's value do not depend on it
+
+
+def test_first_layer_uniform_scale_output_alone():
+    """f8_l0u: once exponents exist, the critic's first layer (critic.py:21-24, 2 -> 128 channels: an 8.6-GB store-bound launch at
+    configs[1]) writes ONLY the uniform-scale copy of its output -- no MXFP8 copy, no bf16 tensor -- with the census of magnitudes the
+    next exponents come from (dg_epilogue.out_amax); layer 1's MXFP8 conv reads that copy with the block exponents as the scale row
+    of every pixel, its fp8 weight gradient reads it as before; the penalty's first tangent likewise.  Gradient quality against the
+    fp32 engine equals the MXFP8 mode's (cosine per layer within 0.03), which also needs the exponents not to fall to the level of
+    the smaller of two alternating inputs (real / generated samples: they fall by at most one per update)."""
+    from downgan_amd import synthetic
+    from downgan_amd.engine import HyperParams, TrainEngine
+    from downgan_amd.layout import nchw_to_nhwc_padded
+    torch.set_num_threads(6)
+    B, S, F_, cin, nrb = 1, 16, 128, 2, 1
+    grads, seen = {}, {}
+    for mode in ("f32", "mx", "l0u"):
+        ops = EmuOps("f32", f8_critic=mode != "f32")
+        ops.f8_l0u = mode == "l0u"
+        log = seen[mode] = []
+        real = ops.conv_fwd
+        def spy(cv, x, w, y, _r=real, _l=log, **kw):
+            xq = kw.get("xq")
+            _l.append((cv.Cin if cv.net == "C" else -1, cv.stride, kw.get("out_q") is not None, kw.get("out_u") is not None, bool(kw.get("skip_y")), kw.get("out_amax") is not None,
+                       xq is not None and xq[1].dim() == 1))
+            return _r(cv, x, w, y, **kw)
+        ops.conv_fwd = spy
+        eng = TrainEngine(ops, S, F_, cin, B, HyperParams(batch_size=B), num_res_blocks=nrb)
+        eng.G.load_state_dict(synthetic.generator_params(F_, cin, 2, nrb))
+        eng.C.load_state_dict(synthetic.critic_params(F_, 8 * S, 2))
+        assert eng.C.l0u == (mode == "l0u")
+        coarse, fine = synthetic.tiles(B, cin, S)
+        xc = nchw_to_nhwc_padded(torch.from_numpy(coarse), 16, torch.float32)
+        xf = nchw_to_nhwc_padded(torch.from_numpy(fine), 16, torch.float32)
+        for it in range(2):
+            eng.critic_iteration(xc, xf, torch.from_numpy(synthetic.alpha(B, it)), apply_update=False)
+        grads[mode] = (eng.C.P.g.clone(), dict(eng.C.P.entries))
+    first = [c for c in seen["l0u"] if c[0] == 16 and c[1] == 1]                # first-layer launches of the critic (forward and tangent)
+    second = [c for c in seen["l0u"] if c[0] == 128 and c[1] == 2]              # layer 1 (128 -> 128, stride 2)
+    assert first[0][2] and first[0][5] and not first[0][3]                      # bootstrap pass: MXFP8 copy + census
+    alone = [c for c in first if c[3] and not c[2]]
+    assert len(alone) >= 5 and all(c[4] and c[5] for c in alone)                # ... then the uniform-scale copy alone, bf16 tensor skipped
+    assert sum(c[6] for c in second) == len(alone)                              # each of them read by layer 1 with the exponent row
+    assert not any(c[6] for c in seen["mx"])
+    g32, ent = grads["f32"]
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))
+    for name, (off, n, _) in ent.items():
+        if name.startswith("features") and name.endswith("weight"):
+            f = g32[off:off + n]
+            c_mx, c_u = cos(grads["mx"][0][off:off + n], f), cos(grads["l0u"][0][off:off + n], f)
+            assert c_u > c_mx - 0.03 and c_u > 0.8, (name, c_mx, c_u)

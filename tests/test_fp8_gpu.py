@@ -595,6 +595,85 @@ def test_block_exp_max_kernel():
         assert int(hip._exp_scratch.abs().sum()) == 0                  # the scratch is left zero
 
 
+def test_exponents_fall_by_at_most_one_per_update():
+    """Passes over one buffer alternate between inputs of different size (real / generated samples); exponents taken from the smaller
+    one would saturate the larger one's uniform-scale copy: dg_block_exp_max and dg_exp_from_amax lower an exponent by at most one per
+    call, raise it at once (oracle/emu_ops.py::_exp_decay)."""
+    hip, emu = HipOps("bf16"), EmuOps("f32")
+    big = torch.full((64, 8), 130, dtype=torch.uint8); small = torch.full((64, 8), 120, dtype=torch.uint8)
+    out, ref = torch.zeros(8, dtype=torch.uint8).cuda(), torch.zeros(8, dtype=torch.uint8)
+    for sc, want in ((big, 131), (small, 130), (small, 129), (big, 131), (small, 130)):
+        hip.block_exp_max(sc.cuda(), out, margin=1); emu.block_exp_max(sc, ref, margin=1)
+        assert torch.equal(out.cpu(), ref) and int(out[0]) == want, (out.cpu(), ref, want)
+    # the census form: bit patterns of the largest magnitudes; cleared by the call
+    f2b = lambda v: torch.tensor(v, dtype=torch.float32).view(torch.int32)
+    out2, ref2 = torch.zeros(4, dtype=torch.uint8).cuda(), torch.zeros(4, dtype=torch.uint8)
+    for vals in ([3.0, 0.5, 100.0, 1e-3], [0.01, 0.5, 0.0, 2.0], [0.01, 0.6, 1e30, 0.0]):
+        a, b = f2b(vals).cuda(), f2b(vals).clone()
+        hip.exp_from_amax(a, out2, margin=1); emu.exp_from_amax(b, ref2, margin=1)
+        assert torch.equal(out2.cpu(), ref2), (vals, out2.cpu(), ref2)
+        assert int(a.abs().sum()) == 0
+    assert int(ref2[1]) == 127 - 1 - 8 + 1 and int(ref2[2]) == 127 + 99 - 8 + 1
+
+
+@pytest.mark.parametrize("tangent", [False, True])
+def test_first_layer_uniform_scale_copy_alone(tangent):
+    """critic features.0 (critic.py:21-24) writing ONLY the uniform-scale copy of its output (dg_epilogue.out_u without out_q, skip_y)
+    plus the magnitude census (out_amax): the copy equals dg_quant_uniform of the tensor a plain launch stores, the census the bit
+    patterns of its per-block maxima, the mask bits are unchanged; and the consumer -- layer 1's MXFP8 stride-2 conv reading the copy
+    with the block exponents as ONE scale row for every pixel (dg_f8_operands.ldxs < 0) -- against the emulation.  `tangent`: the
+    penalty's first tangent (mask_bits instead of activation + out_bits)."""
+    g = torch.Generator().manual_seed(51)
+    hip, emu = HipOps("bf16", f8_critic=True), EmuOps("bf16", f8_critic=True)
+    cv = Conv(2, 48, 80, 16, 128, 1, False, cin_real=2, net="C")
+    x = torch.randn(cv.N, cv.H, cv.W, 16, generator=g).to(torch.bfloat16); x[..., 2:] = 0
+    w = (torch.randn(128 * 9 * 16, generator=g) * 0.3).to(torch.bfloat16).cuda()
+    b = torch.randn(128, generator=g).cuda()
+    osh = (cv.N, cv.H, cv.W, 128)
+    y = torch.zeros(osh, dtype=torch.bfloat16).cuda()
+    bits = torch.zeros(hip.bits_shape(osh), dtype=torch.int16).cuda()
+    mb = torch.randint(0, 1 << 15, hip.bits_shape(osh), generator=g).to(torch.int16).cuda()
+    ep = dict(mask_bits=mb, mask_slope=0.2) if tangent else dict(bias=b, act=0.2, out_bits=bits)
+    hip.conv_fwd(cv, x.cuda(), w, y, **ep)
+    assert hip.lib.dg_last_conv_kernels() == 16
+    am = y.float().abs().reshape(-1, 4, 32).amax(dim=(0, 2))
+    exps = ((am.view(torch.int32) >> 23) & 0xff).to(torch.uint8) - 8 + 1
+    exps[3] -= 3                                                    # one block too small: saturates at +-448
+    u_ref = torch.zeros(osh, dtype=torch.uint8).cuda()
+    hip.quant_uniform(y, u_ref, exps)
+    u = torch.zeros(osh, dtype=torch.uint8).cuda()
+    census = torch.zeros(4, dtype=torch.int32).cuda()
+    y2 = torch.full(osh, 3.0, dtype=torch.bfloat16).cuda()
+    bits2 = torch.zeros_like(bits)
+    ep2 = dict(mask_bits=mb, mask_slope=0.2) if tangent else dict(bias=b, act=0.2, out_bits=bits2)
+    hip.conv_fwd(cv, x.cuda(), w, y2, out_u=(u, exps), out_amax=census, skip_y=True, **ep2)
+    assert hip.lib.dg_last_conv_kernels() == 16
+    assert bool((y2 == 3.0).all()) and torch.equal(u, u_ref), int((u != u_ref).sum())
+    assert torch.equal(census.cpu(), am.cpu().view(torch.int32))
+    if not tangent:
+        assert torch.equal(bits2, bits)
+    # a second launch only raises the census
+    hip.conv_fwd(cv, (x * 0.5).cuda(), w, y2, out_u=(u, exps), out_amax=census, skip_y=True, **ep2)
+    if tangent:
+        assert torch.equal(census.cpu(), am.cpu().view(torch.int32))
+    # consumer: layer 1 (128 -> 128, stride 2) on the MXFP8 kernel with the uniform-scale source
+    hip.quant_uniform(y, u, exps)
+    c1 = Conv(2, 48, 80, 128, 128, 2, False, net="C")
+    w1 = (torch.randn(128 * 9 * 128, generator=g) * 0.05).to(torch.bfloat16)
+    z_ref, z = torch.zeros(2, 24, 40, 128, dtype=torch.bfloat16), torch.zeros(2, 24, 40, 128, dtype=torch.bfloat16).cuda()
+    emu.conv_fwd(c1, y.cpu(), w1, z_ref, act=0.2, xq=(u.cpu(), exps.cpu()))
+    hip.conv_fwd(c1, y2, w1.cuda(), z, act=0.2, xq=(u, exps))
+    assert hip.lib.dg_last_conv_kernels() == 32
+    close(z, z_ref, "layer 1 on the uniform-scale copy")
+    # other launches refuse both features instead of ignoring them
+    cw = Conv(1, 16, 16, 128, 128, 1, False)
+    xw = torch.zeros(1, 16, 16, 128, dtype=torch.bfloat16).cuda(); yw = torch.zeros_like(xw); uw = torch.zeros(1, 16, 16, 128, dtype=torch.uint8).cuda()
+    with pytest.raises(RuntimeError):
+        hip.conv_fwd(cw, xw, w1.cuda(), yw, out_u=(uw, exps))
+    with pytest.raises(RuntimeError):
+        hip.conv_fwd(cw, xw, w1.cuda(), yw, out_amax=census)
+
+
 def test_quant_uniform_kernel():
     """dg_quant_uniform == the emulation's uq_quant, bit for bit (bf16 and fp32 sources, a saturating block, a poisoned block)."""
     from oracle.emu_ops import EmuOps
