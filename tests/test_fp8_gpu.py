@@ -712,7 +712,9 @@ def test_fp8_weight_gradient_quality_at_cfg2_shapes():
     for k, v in res.items():
         assert v["bf16"]["cosine"] >= 0.985, (k, v)
         assert v["fp8"]["cosine"] >= v["fp8_bf16_wgrad"]["cosine"] - 0.02, (k, v)
-        assert v["fp8"]["cosine"] >= (0.88 if k.startswith("features.") and k.endswith(".weight") else 0.85), (k, v)
+        # (biases: sums over all pixels of a cancelling difference; since the generator's tail runs in fp8 too its `fake` differs from the
+        # fp32 engine's by 5 % and `features.0.bias` reads 0.852-0.865 where it read 0.907 with a bf16 tail: profiles/fp8_wgrad_quality_cfg2.json)
+        assert v["fp8"]["cosine"] >= (0.88 if k.startswith("features.") and k.endswith(".weight") else 0.80), (k, v)
 
 
 @pytest.mark.parametrize("case", ["fp8_s2_forward", "fp8_s2_dgrad_classes", "fp8_s1_forward_mask_bits", "fp8_forward_no_u"])
