@@ -64,15 +64,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // 16 fp32 values scaled by `inv` (a power of two), saturated at +-448 and rounded to nearest even -> 16 OCP E4M3 bytes
 typedef __attribute__((ext_vector_type(4))) unsigned int dg_u32x4_t;
-__device__ __forceinline__ dg_u32x4_t pack_fp8x16(const float* v, float inv) {
+// v_cvt_pk_fp8_f32 does not saturate by itself (>= 480 and Inf -> NaN, tools/fp8_cvt_probe.hip) -- unless the wave's MODE.FP16_OVFL bit is
+// set: then every finite overflow becomes +-448 (0x7e / 0xfe), Inf and NaN stay NaN (tools/fp8_cvt_probe2.hip).  pack_fp8x16 leaves the
+// clamp -- one v_med3 per value, a sixth of an fp8 epilogue's VALU work -- to the converter, so every caller brackets its packs with
+// DG_FP8_SAT_ON / DG_FP8_SAT_OFF.  The bit must NOT be left on: under it the MFMAs (bf16 and scaled fp8 alike) turn a NaN in an
+// operand or in the accumulator input into a number and an Inf into 3.4e38 (tools/fp8_cvt_probe3.hip) -- a NaN bias no longer reached
+// the output -- and v_cvt_pk_bf16_f32 rounds a finite |x| >= 3.39e38 to the largest finite bf16 instead of Inf.
+// The macros tie the mode switch to the data: ON rewrites values every pack below depends on, OFF the packed results, so the
+// compiler cannot move a conversion out of the bracket (an asm volatile alone orders memory operations, not VALU ones).
+// (kernels without MFMAs or bf16 conversions -- the stand-alone quantisers -- switch it on once at their entry)
+__device__ __forceinline__ void dg_fp8_saturate_whole_kernel() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 1" ::: "memory"); }
+#define DG_FP8_SAT_ON(dep0, dep1) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1\n\ts_nop 1" : "+v"(dep0), "+v"(dep1))
+#define DG_FP8_SAT_OFF(res0, res1) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0\n\ts_nop 1" : "+v"(res0), "+v"(res1))
+__device__ __forceinline__ dg_u32x4_t pack_fp8x16(const float* v, float inv) {     // (between DG_FP8_SAT_ON and DG_FP8_SAT_OFF)
   dg_u32x4_t o;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     int w = 0;
-    const float a = __builtin_fminf(__builtin_fmaxf(v[4 * q] * inv, -448.f), 448.f), b = __builtin_fminf(__builtin_fmaxf(v[4 * q + 1] * inv, -448.f), 448.f);
-    const float c = __builtin_fminf(__builtin_fmaxf(v[4 * q + 2] * inv, -448.f), 448.f), d = __builtin_fminf(__builtin_fmaxf(v[4 * q + 3] * inv, -448.f), 448.f);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q] * inv, v[4 * q + 1] * inv, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q + 2] * inv, v[4 * q + 3] * inv, w, true);
     o[q] = (unsigned)w;
   }
   return o;

@@ -238,12 +238,15 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
 #pragma unroll
       for (int e = 0; e < CPU; ++e) vu[e] *= leaky_grad(r[e], a.mask_slope);
     }
-    if (f_ob) {
-#pragma unroll
-      for (int e = 0; e < CPU; ++e) ob |= (vu[e] > 0.f ? 1u : 0u) << (u * CPU + e);
-    }
     pk[u] = IO::pack(vu);
     if (F >= 0 ? !(F & 4096) : !a.no_y) __builtin_amdgcn_raw_buffer_store_b128(pk[u], R.rY, offy, u * 16, 0);
+  }
+  if (f_ob) {
+    // bit k = (v[k] > 0), shifted in from the top: compare into VCC, then ob = 2 * ob + carry -- two instructions per value where
+    // the compiler's compare / select / or takes 2.5 (the epilogues are bound by instruction issue)
+#pragma unroll
+    for (int k = 15; k >= 0; --k)
+      asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(ob) : "v"(v[k]) : "vcc");
   }
   if (F >= 0 && (F & 1024)) *ob_ret = ob;      // the caller stores the word itself (gg_im2col_direct_kernel: two words per store)
   else if (F >= 0) { if (f_ob) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ob, R.rbo, boff, 0, 0); }
@@ -256,12 +259,26 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
     if (f_q || f_u) {
       float w[16];
       IO::unpack(pk[0], w); IO::unpack(pk[1], w + 8);
-      unsigned ab = mx_amax_bits16(w);                                // (a NaN / Inf in the block dominates: mx_poison)
+      // largest magnitude of the 16 ROUNDED values as an fp32 bit pattern, taken on the packed bf16 words (v_pk_max_u16: one operation
+      // per two values; as unsigned 16-bit numbers NaN > Inf > every finite value, so a NaN / Inf in the block dominates: mx_poison)
+      typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+      u16x2_t m2 = {0, 0};
+#pragma unroll
+      for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2_t, pk[u2][q] & 0x7fff7fffu));
+      unsigned ab = (unsigned)(m2[0] > m2[1] ? m2[0] : m2[1]) << 16;
       const unsigned ab2 = (unsigned)__shfl_xor((int)ab, 16, 64);
       ab = ab > ab2 ? ab : ab2;
+      // the converter saturates only under MODE.FP16_OVFL (dg_internal.h): on for the packs, off again before anything else runs
+      float iu = inv_u;
+      u32x4_t qv = {0u, 0u, 0u, 0u}, uv = {0u, 0u, 0u, 0u};
+      DG_FP8_SAT_ON(ab, iu);
+      const int e = mx_scale_byte(__uint_as_float(ab));
+      if (f_q) qv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, mx_inv_scale(e)), ab));
+      if (f_u) uv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, iu), ab));
+      DG_FP8_SAT_OFF(qv, uv);
       if (f_q) {
-        const int e = mx_scale_byte(__uint_as_float(ab));
-        const u32x4_t qv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, mx_inv_scale(e)), ab));
         __builtin_amdgcn_raw_buffer_store_b128(qv, R.rq, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
         const bool low_half = ((threadIdx.x >> 4) & 1) == 0;
         unsigned offqs = boff >> 2;                                   // dense scale rows: (rel * Nout + channel) / 32
@@ -271,10 +288,8 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
         }
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, R.rqs, (low_half && boff != DG_OOB_OFF) ? offqs : DG_OOB_OFF, 0, 0);
       }
-      if (f_u) {     // the same rounded values on the tensor-wide exponent of their 32-channel block (a non-finite block is poisoned too)
-        const u32x4_t uv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, inv_u), ab));
+      if (f_u)       // the same rounded values on the tensor-wide exponent of their 32-channel block (a non-finite block is poisoned too)
         __builtin_amdgcn_raw_buffer_store_b128(uv, R.ru, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
-      }
       // running maximum of the block magnitudes this lane has stored (dg_epilogue.out_amax; a dropped pixel's values are not stored)
       if (ab_run && offy != DG_OOB_OFF) *ab_run = *ab_run > ab ? *ab_run : ab;
     }

@@ -41,6 +41,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) quant_mxfp8_kernel(const T* __restrict__ src, long long rows, long long ld, int C,
                                                           unsigned char* __restrict__ q, long long ldq, unsigned char* __restrict__ sc,
                                                           long long ldqs) {
+  dg_fp8_saturate_whole_kernel();
   const int nb = C >> 5;
   const long long total = rows * nb;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -180,6 +181,7 @@ extern "C" int dg_exp_from_amax(void* amax, int nblocks, int margin, void* out, 
 template <typename T>
 __global__ void __launch_bounds__(256) quant_uniform_kernel(const T* __restrict__ src, long long rows, long long ld, int C,
                                                             const unsigned char* __restrict__ exps, unsigned char* __restrict__ q, long long ldq) {
+  dg_fp8_saturate_whole_kernel();
   const int nb = C >> 5;
   const long long total = rows * nb;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
