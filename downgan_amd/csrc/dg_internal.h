@@ -90,6 +90,27 @@ __device__ __forceinline__ dg_u32x4_t pack_fp8x16(const float* v, float inv) {  
 // A block that holds a NaN or an Inf is written as 16 x 0x7F (E4M3 NaN): the clamp above would launder a NaN into -448 and an
 // Inf into +-448, and every later fp8 layer reads only the quantised copy.  `amax_bits` = unsigned maximum of the block's
 // magnitude bit patterns (equal to the bits of the float maximum for finite values; any NaN / Inf pattern is >= 0x7f800000).
+// The same 16 values straight from their PACKED bf16 form (the words a conv epilogue has just stored: p0 = values 0-7, p1 = 8-15):
+// v_cvt_scalef32_pk_fp8_bf16 divides two bf16 by 2^(E - 127), E = the exponent field of `scale` (mantissa ignored, field 0 = 2^-127),
+// and converts -- no unpacking to fp32, no multiply: one VALU slot per two values instead of four.  Under MODE.FP16_OVFL it equals
+// pack_fp8x16 of the unpacked values with factor 2^(127 - E) for every finite bf16 pattern whose quotient is representable in fp32
+// (tools/fp8_cvt_probe4.hip: all 65536 patterns x six exponents), saturates where that product would have overflowed to Inf (as the
+// emulation's clamp does), and turns +-Inf into +-448 -- blocks holding an Inf or a NaN are poisoned by the caller anyway.  Byte order
+// and word select as v_cvt_pk_fp8_f32 (tools/fp8_cvt_probe5.hip).
+__device__ __forceinline__ dg_u32x4_t pack_fp8x16_from_bf16(const dg_u32x4_t& p0, const dg_u32x4_t& p1, float scale) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 dg_bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) short dg_s16x2_t;
+  dg_u32x4_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned d0 = j < 2 ? p0[2 * j] : p1[2 * j - 4], d1 = j < 2 ? p0[2 * j + 1] : p1[2 * j - 3];
+    dg_s16x2_t w = {0, 0};
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(dg_bf16x2_t, d0), scale, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(dg_bf16x2_t, d1), scale, true);
+    o[j] = __builtin_bit_cast(unsigned, w);
+  }
+  return o;
+}
 __device__ __forceinline__ dg_u32x4_t mx_poison(dg_u32x4_t q, unsigned amax_bits) {
   if (amax_bits >= 0x7f800000u) q = dg_u32x4_t{0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu};
   return q;

@@ -198,8 +198,14 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
   // (pure-ALU parts may sit behind uniform branches: only the memory operations have to be unconditional)
   if (f_act) {
     if (a.act_slope >= 0.f && a.act_slope <= 1.f) {          // max(v, v * slope) == leaky(v) for slopes in [0, 1]: 2 operations, not 3
+      // (the products as float2 pairs: v_pk_mul_f32, one VALU slot per two values)
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      const f32x2_t sl2 = {a.act_slope, a.act_slope};
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = __builtin_fmaxf(v[k], v[k] * a.act_slope);
+      for (int k = 0; k < 16; k += 2) {
+        const f32x2_t p = f32x2_t{v[k], v[k + 1]} * sl2;
+        v[k] = __builtin_fmaxf(v[k], p[0]); v[k + 1] = __builtin_fmaxf(v[k + 1], p[1]);
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = leaky(v[k], a.act_slope);
@@ -257,8 +263,6 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
     // from the lane with the lower half.  q has y's pixel stride (in bytes = elements), scales [pixel][Nout / 32]:
     // byte offsets offy / 2 and boff / 4 ((rel * Nout + channel) / 32).
     if (f_q || f_u) {
-      float w[16];
-      IO::unpack(pk[0], w); IO::unpack(pk[1], w + 8);
       // largest magnitude of the 16 ROUNDED values as an fp32 bit pattern, taken on the packed bf16 words (v_pk_max_u16: one operation
       // per two values; as unsigned 16-bit numbers NaN > Inf > every finite value, so a NaN / Inf in the block dominates: mx_poison)
       typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
@@ -271,13 +275,19 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
       const unsigned ab2 = (unsigned)__shfl_xor((int)ab, 16, 64);
       ab = ab > ab2 ? ab : ab2;
       // the converter saturates only under MODE.FP16_OVFL (dg_internal.h): on for the packs, off again before anything else runs
-      float iu = inv_u;
+      // (packs straight from the packed bf16 words, dg_internal.h pack_fp8x16_from_bf16: the divisor's exponent field is the scale byte;
+      // inv_u = 2^(127 - E_u) arrives as the factor the stand-alone quantiser uses)
+      float su = __uint_as_float((254u << 23) - __float_as_uint(inv_u));
       u32x4_t qv = {0u, 0u, 0u, 0u}, uv = {0u, 0u, 0u, 0u};
-      DG_FP8_SAT_ON(ab, iu);
+      DG_FP8_SAT_ON(ab, su);
       const int e = mx_scale_byte(__uint_as_float(ab));
-      if (f_q) qv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, mx_inv_scale(e)), ab));
-      if (f_u) uv = __builtin_bit_cast(u32x4_t, mx_poison(pack_fp8x16(w, iu), ab));
+      if (f_q) qv = __builtin_bit_cast(u32x4_t, pack_fp8x16_from_bf16(pk[0], pk[1], __uint_as_float((unsigned)e << 23)));
+      if (f_u) uv = __builtin_bit_cast(u32x4_t, pack_fp8x16_from_bf16(pk[0], pk[1], su));
       DG_FP8_SAT_OFF(qv, uv);
+      if (__builtin_amdgcn_ballot_w64(ab >= 0x7f800000u)) {          // a NaN / Inf somewhere in the wave (rare: one compare + a scalar branch otherwise)
+        qv = __builtin_bit_cast(u32x4_t, mx_poison(__builtin_bit_cast(dg_u32x4_t, qv), ab));
+        uv = __builtin_bit_cast(u32x4_t, mx_poison(__builtin_bit_cast(dg_u32x4_t, uv), ab));
+      }
       if (f_q) {
         __builtin_amdgcn_raw_buffer_store_b128(qv, R.rq, offy == DG_OOB_OFF ? DG_OOB_OFF : offy >> 1, 0, 0);
         const bool low_half = ((threadIdx.x >> 4) & 1) == 0;
