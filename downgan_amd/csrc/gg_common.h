@@ -272,8 +272,11 @@ __device__ __forceinline__ void epi64_pixel(const GGArgs& a, const EpiRes& R, co
 #pragma unroll
         for (int q = 0; q < 4; ++q) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2_t, pk[u2][q] & 0x7fff7fffu));
       unsigned ab = (unsigned)(m2[0] > m2[1] ? m2[0] : m2[1]) << 16;
-      const unsigned ab2 = (unsigned)__shfl_xor((int)ab, 16, 64);
-      ab = ab > ab2 ? ab : ab2;
+      // the other half of the 32-channel block sits in lane ^ 16, i.e. in the neighbouring 16-lane row: v_permlane16_swap exchanges the
+      // odd rows of one register with the even rows of another (of a copy here), after which the two registers hold, lane by lane, the
+      // pair's two values -- three VALU operations and no trip through the LDS crossbar (ds_bpermute behind __shfl_xor, and its wait)
+      const auto sw = __builtin_amdgcn_permlane16_swap(ab, ab, false, false);
+      ab = sw[0] > sw[1] ? sw[0] : sw[1];
       // the converter saturates only under MODE.FP16_OVFL (dg_internal.h): on for the packs, off again before anything else runs
       // (packs straight from the packed bf16 words, dg_internal.h pack_fp8x16_from_bf16: the divisor's exponent field is the scale byte;
       // inv_u = 2^(127 - E_u) arrives as the factor the stand-alone quantiser uses)
