@@ -4,7 +4,7 @@
 #   2. kernel-trace stats of the same command,
 #   3. the default bench line (with the CPU baseline, the event-free region and the fp8 mode) and the per-layer tables.
 # Only the small summaries are kept (gpurun_out/<tag>_keep/); copy them into profiles/ afterwards.
-TAG=${1:-r04d}
+TAG=${1:-r04e}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
